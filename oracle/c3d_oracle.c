@@ -232,12 +232,17 @@ typedef struct {
     int noe_pot;      /* 0 symmetric soft-square (Huber); 1 X-PLOR soft-square (upper side soft,
                          lower side square); 2 pure square */
     int rep_sep;      /* repel acts on |i-j| >= rep_sep */
+    int ang_mode;     /* (i,i+2) term: 0 lower bound only (d < a0), 1 harmonic both sides */
     double s_noe;     /* 10   chromosome3D.pl:66,1111,1120 */
     double rswitch;   /* 1.0  CNS readdata default [CNS-UNVERIFIED] */
     double asym;      /* 2.0  asymptote slope      [CNS-UNVERIFIED] */
+    double masym;     /* lower-side tail slope for noe_pot 3 (CNS masymptote) [CNS-UNVERIFIED] */
     double k_bond;    /* pseudo-bond force constant (calibrated) */
     double b0;        /* 3.8 A */
     double r0_rep;    /* repel contact distance R0 (scaled by `repel` s) */
+    double k_rep;     /* bead-level repel force-constant multiplier (calibrated) */
+    double k_ang;     /* soft (i,i+2) lower-bound force constant (pseudo-angle), 0 = off */
+    double a0;        /* (i,i+2) lower bound distance */
     double mass;      /* 100  chromosome3D.pl:1416 */
     double fbeta;     /* 10   chromosome3D.pl:1415 */
 } c3o_model;
@@ -267,6 +272,17 @@ static inline double softsq(const c3o_model* m, double delta, double* e) {
     int soft;
     if (m->noe_pot == 0) soft = ad > rs;
     else if (m->noe_pot == 1) soft = delta > rs;
+    else if (m->noe_pot == 3) {
+        if (delta < -rs) {   /* lower side: CNS minus-side soft form a + b/D + c D, c = masym
+                                (msoexponent 1, mrswitch = rswitch), C1-continuous at D = rs */
+            const double mc = m->masym;
+            const double mb = (mc - 2.0 * rs) * rs * rs;
+            const double ma = rs * rs - mb / rs - mc * rs;
+            *e += ma + mb / ad + mc * ad;
+            return -(-mb / (ad * ad) + mc);
+        }
+        soft = delta > rs;
+    }
     else soft = 0;
     if (!soft) { *e += delta * delta; return 2.0 * delta; }
     *e += a + b / ad + c * ad;
@@ -307,8 +323,14 @@ void c3o_energy_force(const c3o_model* m, const int32_t* tgt10, const double* x,
             }
             if (sep >= m->rep_sep && r2 < R2) {
                 const double q = R2 - r2;
-                e_rep += q * q;
-                coef += w_vdw * 4.0 * q;
+                e_rep += m->k_rep * q * q;
+                coef += w_vdw * m->k_rep * 4.0 * q;
+            }
+            if (sep == 2 && m->k_ang > 0 && (m->ang_mode == 1 || r2 < m->a0 * m->a0)) {
+                const double d = sqrt(r2);
+                const double dl = d - m->a0;
+                e_bond += m->k_ang * dl * dl;
+                coef -= w_all * 2.0 * m->k_ang * dl / d;
             }
             if (F && coef != 0.0) {
                 F[3 * i] += coef * dx; F[3 * i + 1] += coef * dy; F[3 * i + 2] += coef * dz;
