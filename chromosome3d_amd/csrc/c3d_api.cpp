@@ -1,0 +1,719 @@
+// c3d_api.cpp — C-ABI host of libc3d.so: context, device buffers, schedule -> launch program,
+// hipGraph replay, timing.  Compiled with hipcc (-x hip) for the HIP runtime API only; the
+// kernels live in c3d_device.hip.
+//
+// Reference boundary: chromosome3D.pl:254-289 (build_models: `cns_solve < dgsa.inp`) and the
+// deck it writes (:882-1846).  What CNS does per model (deck :1574-1829) becomes a flat
+// "program" of SA-step launches; each launch advances every replica by one step.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/c3d.h"
+#include "c3d_host.h"
+#include "c3d_internal.h"
+
+using c3d::fail;
+
+namespace {
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail(C3D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
+    } while (0)
+
+struct Op {
+    c3d::DevStep p;
+    int stage;
+    bool counted;   // a force evaluation = one SA step
+};
+
+// ---- Philox4x32-10 (Salmon et al. SC'11): initial coordinates / velocities ------------------
+inline void philox4x32(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr_in[0], ctr_in[1], ctr_in[2], ctr_in[3]};
+    uint32_t k[2] = {key_in[0], key_in[1]};
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+    memcpy(out, c, sizeof(c));
+}
+inline double u01(uint32_t u) { return ((double)u + 0.5) * (1.0 / 4294967296.0); }
+void normals4(uint64_t seed, uint32_t replica, uint32_t bead, uint32_t purpose, double g[4]) {
+    const uint32_t ctr[4] = {bead, purpose, 0u, 0u};
+    const uint32_t key[2] = {(uint32_t)(seed & 0xFFFFFFFFu) ^ (replica * 0x9E3779B9u), (uint32_t)(seed >> 32) + replica};
+    uint32_t r[4];
+    philox4x32(ctr, key, r);
+    const double two_pi = 6.283185307179586476925286766559;
+    double a = sqrt(-2.0 * log(u01(r[0]))), b = two_pi * u01(r[1]);
+    g[0] = a * cos(b); g[1] = a * sin(b);
+    a = sqrt(-2.0 * log(u01(r[2]))); b = two_pi * u01(r[3]);
+    g[2] = a * cos(b); g[3] = a * sin(b);
+}
+
+}  // namespace
+
+struct c3d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int n = 0, npad = 0, ntiles = 0, nrep = 0, R = 0;
+    c3d_model model;
+    std::vector<c3d_stage> stages;
+    c3d_fire_params fire;
+    float gtol = 0.0f;
+    int check_every = 250;
+    bool use_graph = true;
+    int graph_chunk = 256;
+
+    std::vector<int32_t> h_dist10;   // n*n, from K1 (empty when restraints came from a tbl)
+    c3d::DevBuffers buf{};
+    float* d_feval = nullptr;
+    size_t rep_floats = 0;           // 3*npad per replica
+    bool have_targets = false, have_replicas = false;
+
+    std::vector<Op> program;
+    size_t pc = 0;
+    int parity = 0;
+    long steps_done = 0;
+    std::map<std::tuple<long, int, int>, hipGraphExec_t> graphs;
+
+    double last_ms = 0;
+    long last_steps = 0, last_launches = 0;
+    uint64_t seed = 82364;
+    uint32_t first_rep = 0;
+};
+
+namespace {
+
+void free_replica_buffers(c3d_ctx* c) {
+    for (int k = 0; k < 2; ++k) {
+        if (c->buf.X[k]) hipFree(c->buf.X[k]);
+        if (c->buf.V[k]) hipFree(c->buf.V[k]);
+        if (c->buf.F[k]) hipFree(c->buf.F[k]);
+        if (c->buf.P[k]) hipFree(c->buf.P[k]);
+        if (c->buf.S[k]) hipFree(c->buf.S[k]);
+        c->buf.X[k] = c->buf.V[k] = c->buf.F[k] = c->buf.P[k] = nullptr;
+        c->buf.S[k] = nullptr;
+    }
+    if (c->buf.Vinit) hipFree(c->buf.Vinit);
+    if (c->buf.E) hipFree(c->buf.E);
+    if (c->d_feval) hipFree(c->d_feval);
+    c->buf.Vinit = nullptr; c->buf.E = nullptr; c->d_feval = nullptr;
+    c->have_replicas = false;
+}
+void drop_graphs(c3d_ctx* c) {
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+}
+
+c3d::DevModel dev_model(const c3d_ctx* c) {
+    c3d::DevModel m{};
+    const c3d_model& h = c->model;
+    m.n = c->n; m.npad = c->npad; m.ntiles = c->ntiles; m.nrep = c->nrep;
+    m.noe_pot = h.noe_pot; m.ang_mode = h.ang_mode;
+    m.rs = h.rswitch;
+    m.tail_c = h.asym * h.rswitch;
+    m.tail_b = (m.tail_c - 2.0f * h.rswitch) * h.rswitch * h.rswitch;
+    m.k_bond2 = 2.0f * h.k_bond; m.b0 = h.b0;
+    m.k_ang2 = 2.0f * h.k_ang; m.a0 = h.a0;
+    m.acc = c3d::kAccel / h.mass;
+    const int ndf = std::max(3 * c->n - 3, 1);
+    m.t_fac = h.mass / c3d::kAccel / ((float)ndf * c3d::kBoltz);
+    m.fbeta = h.fbeta;
+    m.inv_n = 1.0f / (float)c->n;
+    return m;
+}
+bool general_tail(const c3d::DevModel& m) { return !(m.tail_b == 0.0f && m.tail_c == 2.0f * m.rs); }
+c3d::DevFire dev_fire(const c3d_ctx* c) {
+    c3d::DevFire f;
+    f.dt_start = c->fire.dt_start; f.dt_max = c->fire.dt_max; f.f_inc = c->fire.f_inc; f.f_dec = c->fire.f_dec;
+    f.alpha_start = c->fire.alpha_start; f.f_alpha = c->fire.f_alpha; f.max_step = c->fire.max_step;
+    f.n_min = c->fire.n_min;
+    return f;
+}
+c3d::DevStep dev_step(const c3d_ctx* c, int kind, float dt, float w_all, float w_vdw, float repel_s, float t_bath) {
+    c3d::DevStep p;
+    p.kind = kind; p.dt = dt; p.w_all = w_all;
+    p.w_noe = w_all * c->model.s_noe;
+    p.w_rep4 = 4.0f * w_vdw * c->model.k_rep;
+    const float rr = repel_s * c->model.r0_rep;
+    p.rep_r2 = rr * rr;
+    p.t_bath = t_bath;
+    return p;
+}
+
+void build_program(c3d_ctx* c) {
+    c->program.clear();
+    int prev_kind = -1;
+    for (size_t s = 0; s < c->stages.size(); ++s) {
+        const c3d_stage& st = c->stages[s];
+        if (st.kind == 2) {
+            c->program.push_back({dev_step(c, 3, 0.0f, st.w_all, st.w_vdw, st.repel_s, 0.0f), (int)s, true});
+            for (int k = 0; k < st.nsteps; ++k)
+                c->program.push_back({dev_step(c, 2, 0.0f, st.w_all, st.w_vdw, st.repel_s, 0.0f), (int)s, true});
+        } else {
+            if (prev_kind == 2 || prev_kind == -1)
+                c->program.push_back({dev_step(c, 4, 0.0f, st.w_all, st.w_vdw, st.repel_s, st.t_bath), (int)s, false});
+            for (int k = 0; k < st.nsteps; ++k)
+                c->program.push_back({dev_step(c, st.kind, st.dt, st.w_all, st.w_vdw, st.repel_s, st.t_bath), (int)s, true});
+        }
+        prev_kind = st.kind;
+    }
+    c->pc = 0;
+    drop_graphs(c);
+}
+
+int upload_targets(c3d_ctx* c, const std::vector<float>& enc) {
+    if (c->buf.tgt) { hipFree(c->buf.tgt); c->buf.tgt = nullptr; }
+    HIP_TRY(hipMalloc(&c->buf.tgt, sizeof(float) * enc.size()));
+    HIP_TRY(hipMemcpy(c->buf.tgt, enc.data(), sizeof(float) * enc.size(), hipMemcpyHostToDevice));
+    return C3D_OK;
+}
+
+void set_dims(c3d_ctx* c, int n) {
+    c->n = n;
+    c->npad = (n + 63) / 64 * 64;
+    c->ntiles = (n + c3d::kTileRows - 1) / c3d::kTileRows;
+    c->rep_floats = (size_t)3 * c->npad;
+}
+
+// AoS host (nrep*n*3) -> SoA padded device layout
+void pack(const c3d_ctx* c, const float* aos, std::vector<float>& soa, bool pad_far) {
+    soa.assign(c->rep_floats * c->nrep, 0.0f);
+    for (int r = 0; r < c->nrep; ++r) {
+        float* base = soa.data() + c->rep_floats * r;
+        for (int comp = 0; comp < 3; ++comp) {
+            for (int i = 0; i < c->n; ++i) base[(size_t)comp * c->npad + i] = aos[((size_t)r * c->n + i) * 3 + comp];
+            if (pad_far)
+                for (int i = c->n; i < c->npad; ++i) base[(size_t)comp * c->npad + i] = c3d::kPadCoord * (float)(comp + 1) + 16.0f * (float)(i - c->n);
+        }
+    }
+}
+void unpack(const c3d_ctx* c, const std::vector<float>& soa, float* aos) {
+    for (int r = 0; r < c->nrep; ++r) {
+        const float* base = soa.data() + c->rep_floats * r;
+        for (int comp = 0; comp < 3; ++comp)
+            for (int i = 0; i < c->n; ++i) aos[((size_t)r * c->n + i) * 3 + comp] = base[(size_t)comp * c->npad + i];
+    }
+}
+
+int launch_op(c3d_ctx* c, const Op& op) {
+    const c3d::DevModel m = dev_model(c);
+    hipError_t e = c3d::launch_step(m, op.p, dev_fire(c), c->buf, c->parity, general_tail(m), c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
+    c->parity ^= 1;
+    return C3D_OK;
+}
+
+// run program ops [pc, pc + nops): eager or via cached graphs
+int run_ops(c3d_ctx* c, size_t nops) {
+    size_t done = 0;
+    while (done < nops) {
+        const size_t chunk = std::min<size_t>(nops - done, c->use_graph ? (size_t)c->graph_chunk : nops - done);
+        if (!c->use_graph || chunk < 8) {
+            for (size_t k = 0; k < chunk; ++k) {
+                int rc = launch_op(c, c->program[c->pc + k]);
+                if (rc) return rc;
+            }
+        } else {
+            // homogeneous FIRE ranges (same stage, all kind 2) share one graph regardless of pc
+            const Op& first = c->program[c->pc];
+            const Op& last = c->program[c->pc + chunk - 1];
+            long sig = (long)c->pc;
+            if (first.p.kind == 2 && last.p.kind == 2 && first.stage == last.stage) sig = -(long)(first.stage + 1);
+            const auto key = std::make_tuple(sig, (int)chunk, c->parity);
+            auto it = c->graphs.find(key);
+            if (it == c->graphs.end()) {
+                hipGraph_t g = nullptr;
+                HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                const int p0 = c->parity;
+                int rc = C3D_OK;
+                for (size_t k = 0; k < chunk && rc == C3D_OK; ++k) rc = launch_op(c, c->program[c->pc + k]);
+                hipError_t ce = hipStreamEndCapture(c->stream, &g);
+                c->parity = p0;
+                if (rc) { if (g) hipGraphDestroy(g); return rc; }
+                if (ce != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+                hipGraphExec_t ge = nullptr;
+                hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                hipGraphDestroy(g);
+                if (ie != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+                it = c->graphs.emplace(key, ge).first;
+            }
+            HIP_TRY(hipGraphLaunch(it->second, c->stream));
+            if (chunk & 1) c->parity ^= 1;
+        }
+        for (size_t k = 0; k < chunk; ++k)
+            if (c->program[c->pc + k].counted) { ++c->steps_done; ++c->last_steps; }
+        c->last_launches += (long)chunk;
+        c->pc += chunk;
+        done += chunk;
+    }
+    return C3D_OK;
+}
+
+int begin_timing(c3d_ctx* c) {
+    c->last_ms = 0; c->last_steps = 0; c->last_launches = 0;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return C3D_OK;
+}
+int end_timing(c3d_ctx* c) {
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    return C3D_OK;
+}
+
+// max over replicas of the RMS force from the FIRE partial sums of the current parity
+int max_rms_force(c3d_ctx* c, double* out) {
+    std::vector<float> h((size_t)c->nrep * c->ntiles * 4);
+    HIP_TRY(hipMemcpyAsync(h.data(), c->buf.P[c->parity], sizeof(float) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double worst = 0;
+    for (int r = 0; r < c->nrep; ++r) {
+        double ff = 0;
+        for (int t = 0; t < c->ntiles; ++t) ff += h[((size_t)r * c->ntiles + t) * 4 + 1];
+        worst = std::max(worst, sqrt(ff / (3.0 * c->n)));
+    }
+    *out = worst;
+    return C3D_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int c3d_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void c3d_default_model(c3d_model* m) {
+    if (!m) return;
+    m->min_sep = 5; m->noe_pot = 1; m->rep_sep = 2; m->ang_mode = 1;
+    m->s_noe = 10.0f; m->rswitch = 1.0f; m->asym = 2.0f;
+    m->k_bond = 700.0f; m->b0 = 3.8f;
+    m->k_ang = 60.0f; m->a0 = 7.4f;
+    m->r0_rep = 6.0f; m->k_rep = 1.0f;
+    m->mass = 100.0f; m->fbeta = 10.0f;
+}
+extern "C" void c3d_default_fire(c3d_fire_params* f) {
+    if (!f) return;
+    f->dt_start = 0.002f; f->dt_max = 0.02f; f->f_inc = 1.1f; f->f_dec = 0.5f;
+    f->alpha_start = 0.1f; f->f_alpha = 0.99f; f->max_step = 0.5f; f->n_min = 5;
+}
+extern "C" int c3d_default_schedule(c3d_stage* st, int cap, int min_steps) {
+    std::vector<c3d_stage> v;
+    // regularisation (deck :1631-1645: 100 + 100 minimiser steps, weights * 1, vdw 20, repel 0.5)
+    v.push_back({2, 200, 0.0f, 1.0f, 20.0f, 0.5f, 0.0f});
+    // hot stages (deck :1649-1700): 1000 steps at 2000 K, dt 0.003
+    const float hot_t = 2000.0f, hot_dt = 0.003f;
+    const int hot_n[5] = {125, 125, 125, 500, 125};
+    const float hot_w[5] = {0.1f, 0.2f, 0.2f, 0.4f, 1.0f};
+    const float hot_v[5] = {20.0f, 20.0f, 0.01f, 0.003f, 0.003f};
+    const float hot_r[5] = {0.5f, 0.5f, 0.9f, 0.9f, 0.9f};
+    for (int k = 0; k < 5; ++k) v.push_back({0, hot_n[k], hot_dt, hot_w[k], hot_v[k], hot_r[k], hot_t});
+    // slow cool (deck :1740-1782): ncycle = 80, 81 passes of int(1000/80) = 12 steps, dt 0.005
+    const int ncycle = (int)(hot_t / 25.0f);
+    const int nstep = 1000 / ncycle;
+    const double vdw_step = pow(4.0 / 0.003, 1.0 / ncycle);
+    const double rad_step = (1.0 - 0.85) / ncycle;
+    double radius = 1.0, kv = 0.003, bath = hot_t;
+    for (int i = 0; i <= ncycle; ++i) {
+        v.push_back({1, nstep, 0.005f, 1.0f, (float)kv, (float)radius, (float)bath});
+        radius = std::max(0.85, radius - rad_step);
+        kv = std::min(4.0, kv * vdw_step);
+        bath -= 25.0;
+    }
+    // final minimisation (deck :1790-1803): weights * 1
+    v.push_back({2, min_steps, 0.0f, 1.0f, 1.0f, 0.85f, 0.0f});
+    if (st) for (int k = 0; k < (int)v.size() && k < cap; ++k) st[k] = v[k];
+    return (int)v.size();
+}
+
+extern "C" int c3d_create(int device, c3d_ctx** out) {
+    if (!out) return fail(C3D_ERR_INVALID, "c3d_create: null out");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(C3D_ERR_NO_DEVICE, "no HIP device visible: libc3d has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(C3D_ERR_INVALID, "c3d_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(C3D_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libc3d is built for gfx950 only");
+    c3d_ctx* c = new c3d_ctx();
+    c->device = device;
+    c3d_default_model(&c->model);
+    c3d_default_fire(&c->fire);
+    c->stages.resize(c3d_default_schedule(nullptr, 0, 3000));
+    c3d_default_schedule(c->stages.data(), (int)c->stages.size(), 3000);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(C3D_ERR_HIP, "cannot create HIP stream/events");
+    }
+    *out = c;
+    return C3D_OK;
+}
+
+extern "C" void c3d_destroy(c3d_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    drop_graphs(c);
+    free_replica_buffers(c);
+    if (c->buf.tgt) hipFree(c->buf.tgt);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int c3d_set_model(c3d_ctx* c, const c3d_model* m) {
+    if (!c || !m) return fail(C3D_ERR_INVALID, "c3d_set_model: null argument");
+    if (m->mass <= 0 || m->rswitch <= 0 || m->min_sep < 1 || m->rep_sep < 1 || m->noe_pot < 0 || m->noe_pot > 2)
+        return fail(C3D_ERR_INVALID, "c3d_set_model: parameter out of range");
+    if (c->have_targets && (m->min_sep != c->model.min_sep || m->rep_sep != c->model.rep_sep))
+        return fail(C3D_ERR_INVALID, "c3d_set_model: min_sep/rep_sep must be set before the targets are built");
+    c->model = *m;
+    build_program(c);
+    return C3D_OK;
+}
+
+extern "C" int c3d_set_schedule(c3d_ctx* c, const c3d_stage* st, int n_stages, const c3d_fire_params* fire, float gtol,
+                                int check_every) {
+    if (!c || !st || n_stages < 1) return fail(C3D_ERR_INVALID, "c3d_set_schedule: bad arguments");
+    for (int k = 0; k < n_stages; ++k)
+        if (st[k].kind < 0 || st[k].kind > 2 || st[k].nsteps < 0) return fail(C3D_ERR_INVALID, "c3d_set_schedule: bad stage");
+    c->stages.assign(st, st + n_stages);
+    if (fire) c->fire = *fire;
+    c->gtol = gtol;
+    if (check_every > 0) c->check_every = check_every;
+    build_program(c);
+    return C3D_OK;
+}
+
+extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
+    if (!c || !key) return fail(C3D_ERR_INVALID, "c3d_set_option: null argument");
+    if (!strcmp(key, "use_graph")) { c->use_graph = value != 0; return C3D_OK; }
+    if (!strcmp(key, "graph_chunk")) {
+        if (value < 8) return fail(C3D_ERR_INVALID, "graph_chunk must be >= 8");
+        c->graph_chunk = (int)value & ~1;   // even: a chunk returns to the starting parity
+        drop_graphs(c);
+        return C3D_OK;
+    }
+    return fail(C3D_ERR_INVALID, std::string("unknown option ") + key);
+}
+
+extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alpha, double K) {
+    if (!c || !IF || n < 2) return fail(C3D_ERR_INVALID, "c3d_set_if_matrix: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    free_replica_buffers(c);
+    set_dims(c, n);
+    const size_t nn = (size_t)n * n;
+    double *dIF = nullptr, *dP = nullptr, *dpart = nullptr;
+    int32_t* ddist = nullptr;
+    const int npartial = 64;
+    if (c->buf.tgt) { hipFree(c->buf.tgt); c->buf.tgt = nullptr; }
+    HIP_TRY(hipMalloc(&dIF, sizeof(double) * nn));
+    HIP_TRY(hipMalloc(&dP, sizeof(double) * nn));
+    HIP_TRY(hipMalloc(&dpart, sizeof(double) * npartial));
+    HIP_TRY(hipMalloc(&ddist, sizeof(int32_t) * nn));
+    HIP_TRY(hipMalloc(&c->buf.tgt, sizeof(float) * (size_t)n * c->npad));
+    HIP_TRY(hipMemcpyAsync(dIF, IF, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
+    hipError_t e = c3d::launch_if_to_target(dIF, n, c->npad, alpha, K, c->model.min_sep, c->model.rep_sep, dP, dpart,
+                                            npartial, ddist, c->buf.tgt, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("K1 launch: ") + hipGetErrorString(e));
+    c->h_dist10.resize(nn);
+    HIP_TRY(hipMemcpyAsync(c->h_dist10.data(), ddist, sizeof(int32_t) * nn, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(dIF); hipFree(dP); hipFree(dpart); hipFree(ddist);
+    int R = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (j - i >= c->model.min_sep && c->h_dist10[(size_t)i * n + j] > 0) ++R;
+    c->R = R;
+    c->have_targets = true;
+    build_program(c);
+    return C3D_OK;
+}
+
+extern "C" int c3d_set_restraints(c3d_ctx* c, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10) {
+    if (!c || n < 2 || R < 0 || (R > 0 && (!ri || !rj || !rt10))) return fail(C3D_ERR_INVALID, "c3d_set_restraints: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    free_replica_buffers(c);
+    set_dims(c, n);
+    std::vector<float> enc((size_t)n * c->npad);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < c->npad; ++j) {
+            const int sep = std::abs(i - j);
+            enc[(size_t)i * c->npad + j] = c3d::encode_target_host(0.0f, j < n && sep >= c->model.rep_sep);
+        }
+    for (int k = 0; k < R; ++k) {
+        const int i = ri[k] - 1, j = rj[k] - 1;
+        if (i < 0 || j < 0 || i >= n || j >= n || i == j) return fail(C3D_ERR_INVALID, "c3d_set_restraints: index out of range");
+        if (rt10[k] <= 0) continue;
+        const float t = (float)((double)rt10[k] / 10.0);
+        const bool rep = std::abs(i - j) >= c->model.rep_sep;
+        enc[(size_t)i * c->npad + j] = c3d::encode_target_host(t, rep);
+        enc[(size_t)j * c->npad + i] = c3d::encode_target_host(t, rep);
+    }
+    int rc = upload_targets(c, enc);
+    if (rc) return rc;
+    c->h_dist10.clear();
+    c->R = R;
+    c->have_targets = true;
+    build_program(c);
+    return C3D_OK;
+}
+
+extern "C" int c3d_get_dist10(c3d_ctx* c, int32_t* out) {
+    if (!c || !out) return fail(C3D_ERR_INVALID, "c3d_get_dist10: null argument");
+    if (c->h_dist10.empty()) return fail(C3D_ERR_INVALID, "c3d_get_dist10: targets were not built from an IF matrix");
+    memcpy(out, c->h_dist10.data(), sizeof(int32_t) * c->h_dist10.size());
+    return C3D_OK;
+}
+extern "C" int c3d_num_beads(const c3d_ctx* c) { return c ? c->n : 0; }
+extern "C" int c3d_num_restraints(const c3d_ctx* c) { return c ? c->R : 0; }
+
+extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t first_replica) {
+    if (!c || nrep < 1) return fail(C3D_ERR_INVALID, "c3d_init_replicas: bad arguments");
+    if (!c->have_targets) return fail(C3D_ERR_INVALID, "c3d_init_replicas: set the IF matrix / restraints first");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->have_replicas && nrep != c->nrep) free_replica_buffers(c);
+    c->nrep = nrep; c->seed = seed; c->first_rep = first_replica;
+    const size_t nf = c->rep_floats * nrep;
+    if (!c->have_replicas) {
+        drop_graphs(c);
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipMalloc(&c->buf.X[k], sizeof(float) * nf));
+            HIP_TRY(hipMalloc(&c->buf.V[k], sizeof(float) * nf));
+            HIP_TRY(hipMalloc(&c->buf.F[k], sizeof(float) * nf));
+            HIP_TRY(hipMalloc(&c->buf.P[k], sizeof(float) * 4 * (size_t)nrep * c->ntiles));
+            HIP_TRY(hipMalloc(&c->buf.S[k], sizeof(c3d::FireState) * nrep));
+        }
+        HIP_TRY(hipMalloc(&c->buf.Vinit, sizeof(float) * nf));
+        HIP_TRY(hipMalloc(&c->buf.E, sizeof(double) * 4 * nrep));
+        HIP_TRY(hipMalloc(&c->d_feval, sizeof(float) * nf));
+        c->have_replicas = true;
+    }
+    // random coil (step b0) and Maxwell(0.5 K) velocities (deck :1646-1648), Philox keyed (seed, replica)
+    const int n = c->n;
+    std::vector<float> x((size_t)nrep * n * 3), v((size_t)nrep * n * 3);
+    const double sigma = sqrt((double)c3d::kBoltz * 0.5 * (double)c3d::kAccel / (double)c->model.mass);
+    for (int r = 0; r < nrep; ++r) {
+        const uint32_t rid = first_replica + (uint32_t)r;
+        std::vector<double> xd((size_t)3 * n);
+        double px = 0, py = 0, pz = 0;
+        for (int i = 0; i < n; ++i) {
+            if (i > 0) {
+                double g[4];
+                normals4(seed, rid, (uint32_t)i, 0u, g);
+                double nrm = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+                if (nrm < 1e-12) { g[0] = 1; g[1] = g[2] = 0; nrm = 1; }
+                px += (double)c->model.b0 * g[0] / nrm; py += (double)c->model.b0 * g[1] / nrm; pz += (double)c->model.b0 * g[2] / nrm;
+            }
+            xd[3 * i] = px; xd[3 * i + 1] = py; xd[3 * i + 2] = pz;
+        }
+        double cx = 0, cy = 0, cz = 0;
+        for (int i = 0; i < n; ++i) { cx += xd[3 * i]; cy += xd[3 * i + 1]; cz += xd[3 * i + 2]; }
+        cx /= n; cy /= n; cz /= n;
+        for (int i = 0; i < n; ++i) {
+            x[((size_t)r * n + i) * 3 + 0] = (float)(xd[3 * i] - cx);
+            x[((size_t)r * n + i) * 3 + 1] = (float)(xd[3 * i + 1] - cy);
+            x[((size_t)r * n + i) * 3 + 2] = (float)(xd[3 * i + 2] - cz);
+            double g[4];
+            normals4(seed, rid, (uint32_t)i, 1u, g);
+            v[((size_t)r * n + i) * 3 + 0] = (float)(sigma * g[0]);
+            v[((size_t)r * n + i) * 3 + 1] = (float)(sigma * g[1]);
+            v[((size_t)r * n + i) * 3 + 2] = (float)(sigma * g[2]);
+        }
+    }
+    std::vector<float> soa;
+    pack(c, x.data(), soa, true);
+    HIP_TRY(hipMemcpy(c->buf.X[0], soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->buf.X[1], soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
+    pack(c, v.data(), soa, false);
+    HIP_TRY(hipMemcpy(c->buf.Vinit, soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMemset(c->buf.V[k], 0, sizeof(float) * nf));
+        HIP_TRY(hipMemset(c->buf.F[k], 0, sizeof(float) * nf));
+        HIP_TRY(hipMemset(c->buf.P[k], 0, sizeof(float) * 4 * (size_t)nrep * c->ntiles));
+        HIP_TRY(hipMemset(c->buf.S[k], 0, sizeof(c3d::FireState) * nrep));
+    }
+    HIP_TRY(hipMemset(c->d_feval, 0, sizeof(float) * nf));
+    c->pc = 0; c->parity = 0; c->steps_done = 0;
+    return C3D_OK;
+}
+
+extern "C" int c3d_set_coords(c3d_ctx* c, const float* xyz) {
+    if (!c || !xyz) return fail(C3D_ERR_INVALID, "c3d_set_coords: null argument");
+    if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_set_coords: call c3d_init_replicas first");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float> soa;
+    pack(c, xyz, soa, true);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->buf.X[c->parity], soa.data(), sizeof(float) * soa.size(), hipMemcpyHostToDevice));
+    return C3D_OK;
+}
+static int get_soa(c3d_ctx* c, const float* dev, float* aos) {
+    std::vector<float> soa(c->rep_floats * c->nrep);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(soa.data(), dev, sizeof(float) * soa.size(), hipMemcpyDeviceToHost));
+    unpack(c, soa, aos);
+    return C3D_OK;
+}
+extern "C" int c3d_get_coords(c3d_ctx* c, float* xyz) {
+    if (!c || !xyz || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_get_coords: bad state");
+    HIP_TRY(hipSetDevice(c->device));
+    return get_soa(c, c->buf.X[c->parity], xyz);
+}
+extern "C" int c3d_get_velocities(c3d_ctx* c, float* v) {
+    if (!c || !v || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_get_velocities: bad state");
+    HIP_TRY(hipSetDevice(c->device));
+    return get_soa(c, c->buf.V[c->parity], v);
+}
+
+extern "C" long c3d_schedule_length(const c3d_ctx* c) {
+    if (!c) return 0;
+    long n = 0;
+    for (const Op& op : c->program) n += op.counted;
+    return n;
+}
+extern "C" long c3d_steps_done(const c3d_ctx* c) { return c ? c->steps_done : 0; }
+
+extern "C" int c3d_run_steps(c3d_ctx* c, long nsteps, long* done) {
+    if (!c || nsteps < 0) return fail(C3D_ERR_INVALID, "c3d_run_steps: bad arguments");
+    if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_run_steps: call c3d_init_replicas first");
+    HIP_TRY(hipSetDevice(c->device));
+    // number of program ops that contain exactly nsteps counted steps (or the rest of the program)
+    size_t nops = 0;
+    long counted = 0;
+    while (c->pc + nops < c->program.size() && counted < nsteps) {
+        counted += c->program[c->pc + nops].counted;
+        ++nops;
+    }
+    int rc = begin_timing(c);
+    if (rc) return rc;
+    rc = run_ops(c, nops);
+    if (rc) return rc;
+    rc = end_timing(c);
+    if (rc) return rc;
+    if (done) *done = counted;
+    return C3D_OK;
+}
+
+extern "C" int c3d_centre(c3d_ctx* c) {
+    if (!c || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_centre: bad state");
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = c3d::launch_centre(dev_model(c), c->buf, c->parity, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("centre launch: ") + hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C3D_OK;
+}
+
+extern "C" int c3d_run(c3d_ctx* c) {
+    if (!c) return fail(C3D_ERR_INVALID, "c3d_run: null context");
+    if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_run: call c3d_init_replicas first");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = begin_timing(c);
+    if (rc) return rc;
+    const int last_stage = (int)c->stages.size() - 1;
+    const bool early = c->gtol > 0.0f && last_stage >= 0 && c->stages[last_stage].kind == 2;
+    // everything before the final minimisation
+    size_t nfixed = c->program.size() - c->pc;
+    if (early) {
+        nfixed = 0;
+        while (c->pc + nfixed < c->program.size() && c->program[c->pc + nfixed].stage != last_stage) ++nfixed;
+    }
+    rc = run_ops(c, nfixed);
+    if (rc) return rc;
+    if (early) {
+        // FIRE begin + chunks of check_every steps until every replica's RMS force < gtol
+        if (c->pc < c->program.size()) { rc = run_ops(c, 1); if (rc) return rc; }
+        while (c->pc < c->program.size()) {
+            const size_t chunk = std::min<size_t>((size_t)(c->check_every & ~1), c->program.size() - c->pc);
+            rc = run_ops(c, chunk);
+            if (rc) return rc;
+            double rms = 0;
+            rc = max_rms_force(c, &rms);
+            if (rc) return rc;
+            if (rms < c->gtol) break;
+        }
+        c->pc = c->program.size();
+    }
+    hipError_t e = c3d::launch_centre(dev_model(c), c->buf, c->parity, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("centre launch: ") + hipGetErrorString(e));
+    return end_timing(c);
+}
+
+extern "C" int c3d_last_timing(const c3d_ctx* c, double* ms_total, long* steps, long* launches) {
+    if (!c) return fail(C3D_ERR_INVALID, "c3d_last_timing: null context");
+    if (ms_total) *ms_total = c->last_ms;
+    if (steps) *steps = c->last_steps;
+    if (launches) *launches = c->last_launches;
+    return C3D_OK;
+}
+
+extern "C" int c3d_eval(c3d_ctx* c, float w_all, float w_vdw, float repel_s, float* F, double* e) {
+    if (!c || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_eval: bad state");
+    HIP_TRY(hipSetDevice(c->device));
+    const c3d::DevModel m = dev_model(c);
+    const c3d::DevStep p = dev_step(c, 3, 0.0f, w_all, w_vdw, repel_s, 0.0f);
+    if (F) {
+        hipError_t err = c3d::launch_eval_forces(m, p, c->buf, c->parity, c->d_feval, general_tail(m), c->stream);
+        if (err != hipSuccess) return fail(C3D_ERR_HIP, std::string("eval launch: ") + hipGetErrorString(err));
+        int rc = get_soa(c, c->d_feval, F);
+        if (rc) return rc;
+    }
+    if (e) {
+        hipError_t err = c3d::launch_energy(m, p, c->buf, c->parity, c->model.s_noe, c->model.k_rep, 0, c->stream);
+        if (err != hipSuccess) return fail(C3D_ERR_HIP, std::string("energy launch: ") + hipGetErrorString(err));
+        std::vector<double> h((size_t)4 * c->nrep);
+        HIP_TRY(hipMemcpyAsync(h.data(), c->buf.E, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int r = 0; r < c->nrep; ++r) for (int k = 0; k < 3; ++k) e[3 * r + k] = h[4 * r + k];
+    }
+    return C3D_OK;
+}
+
+extern "C" int c3d_get_energies(c3d_ctx* c, double* e) {
+    if (!c || !e) return fail(C3D_ERR_INVALID, "c3d_get_energies: null argument");
+    float repel_s = 0.85f;
+    if (!c->stages.empty()) repel_s = c->stages.back().repel_s;
+    return c3d_eval(c, 1.0f, 1.0f, repel_s, nullptr, e);
+}
+
+extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
+    if (!c || !rank) return fail(C3D_ERR_INVALID, "c3d_rank: null argument");
+    std::vector<double> e((size_t)3 * std::max(c->nrep, 1));
+    int rc = c3d_get_energies(c, e.data());
+    if (rc) return rc;
+    std::vector<int32_t> idx(c->nrep);
+    for (int r = 0; r < c->nrep; ++r) idx[r] = r;
+    // ascending int(E_noe) (get_cns_energy :617 truncates), ties by replica id
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return (long long)e[3 * a] < (long long)e[3 * b]; });
+    for (int r = 0; r < c->nrep; ++r) rank[r] = idx[r];
+    return C3D_OK;
+}

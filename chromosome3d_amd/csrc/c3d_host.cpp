@@ -1,0 +1,307 @@
+// c3d_host.cpp — host-side formats of the reference (no device code): IF matrix reader,
+// <ID>.dist / <ID>.rr / contact.tbl writers, contact.tbl reader, PDB writer/reader,
+// restraint-satisfaction report and the Spearman(IF, d) metric.  Part of libc3d.so.
+//
+// Reference (file:line): chromosome3D.pl:116-129,164-179 (matrix parse), :156-161 (.dist),
+// :181-206 (.rr, Perl string sort), :340-362 (contact.tbl), :497-520 (tbl parse rules),
+// :447-485,581-600,716-729 (assessment), :853-857,208-215 (final PDB layout),
+// :93-94 (pseudo-sequence), spearman_IF_pdb.pl:42-70 (metric).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/c3d.h"
+#include "c3d_host.h"
+
+namespace c3d {
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+}  // namespace c3d
+
+using c3d::fail;
+
+extern "C" const char* c3d_last_error(void) { return c3d::g_err.c_str(); }
+extern "C" const char* c3d_version(void) { return "chromosome3d_amd 0.1 (gfx950)"; }
+extern "C" void c3d_free(void* p) { free(p); }
+
+static bool read_file(const char* path, std::string& out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, k);
+    fclose(f);
+    return true;
+}
+static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; }
+
+extern "C" int c3d_parse_if_file(const char* path, double** IF, int* n_out) {
+    if (!path || !IF || !n_out) return fail(C3D_ERR_INVALID, "c3d_parse_if_file: null argument");
+    std::string txt;
+    if (!read_file(path, txt)) return fail(C3D_ERR_IO, std::string("cannot read IF matrix ") + path);
+    // N = number of fields on the first non-empty line (calc_len_IF)
+    size_t p = 0;
+    int n = 0;
+    bool in_tok = false;
+    while (p < txt.size() && txt[p] != '\n') {
+        const bool ws = is_ws(txt[p]);
+        if (!ws && !in_tok) { ++n; in_tok = true; }
+        if (ws) in_tok = false;
+        ++p;
+    }
+    if (n < 1) return fail(C3D_ERR_IO, std::string("IF matrix has an empty first line: ") + path);
+    const size_t nn = (size_t)n * n;
+    double* m = (double*)malloc(sizeof(double) * nn);
+    if (!m) return fail(C3D_ERR_NOMEM, "out of memory");
+    size_t cnt = 0;
+    const char* s = txt.c_str();
+    while (*s) {
+        while (*s && is_ws(*s)) ++s;
+        if (!*s) break;
+        char* e;
+        const double v = strtod(s, &e);
+        if (e == s) { free(m); return fail(C3D_ERR_IO, std::string("non-numeric token in IF matrix ") + path); }
+        if (cnt < nn) m[cnt] = v;
+        ++cnt;
+        s = e;
+    }
+    if (cnt != nn) {
+        free(m);
+        char b[256];
+        snprintf(b, sizeof b, "IF matrix %s: expected %d x %d = %zu numbers, found %zu", path, n, n, nn, cnt);
+        return fail(C3D_ERR_IO, b);
+    }
+    *IF = m;
+    *n_out = n;
+    return C3D_OK;
+}
+
+namespace {
+struct RrRow {
+    int i, j;
+    int32_t t10;
+    char key[24];
+};
+}  // namespace
+
+extern "C" int c3d_write_front_half(const int32_t* dist10, int n, int min_sep, const char* dist_path, const char* rr_path,
+                                    const char* tbl_path, int* n_restraints) {
+    if (!dist10 || n < 1) return fail(C3D_ERR_INVALID, "c3d_write_front_half: bad arguments");
+    if (dist_path) {
+        FILE* f = fopen(dist_path, "w");
+        if (!f) return fail(C3D_ERR_IO, std::string("cannot write ") + dist_path);
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < n; ++j) {
+                const int32_t t = dist10[(size_t)i * n + j];
+                const int32_t a = t < 0 ? -t : t;
+                fprintf(f, "%s%d.%d ", t < 0 ? "-" : "", a / 10, a % 10);
+            }
+            fputc('\n', f);
+        }
+        fclose(f);
+    }
+    std::vector<RrRow> rows;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const int32_t t = dist10[(size_t)i * n + j];
+            if (j - i < min_sep || t <= 0) continue;
+            RrRow r;
+            r.i = i + 1; r.j = j + 1; r.t10 = t;
+            snprintf(r.key, sizeof r.key, "%d %d", r.i, r.j);
+            rows.push_back(r);
+        }
+    // Perl `sort keys`: byte-wise string order of "i j"
+    std::sort(rows.begin(), rows.end(), [](const RrRow& a, const RrRow& b) { return strcmp(a.key, b.key) < 0; });
+    if (rr_path) {
+        FILE* f = fopen(rr_path, "w");
+        if (!f) return fail(C3D_ERR_IO, std::string("cannot write ") + rr_path);
+        for (const RrRow& r : rows)
+            fprintf(f, "%d %d %d.%d0 %d.%d0 1.0\n", r.i, r.j, r.t10 / 10, r.t10 % 10, r.t10 / 10, r.t10 % 10);
+        fclose(f);
+    }
+    if (tbl_path) {
+        FILE* f = fopen(tbl_path, "w");
+        if (!f) return fail(C3D_ERR_IO, std::string("cannot write ") + tbl_path);
+        for (const RrRow& r : rows)
+            fprintf(f, "assign45 (resid %3d and name ca) (resid %3d and name ca) %d.%d0 0.00 0.00\n", r.i, r.j, r.t10 / 10,
+                    r.t10 % 10);
+        fclose(f);
+    }
+    if (n_restraints) *n_restraints = (int)rows.size();
+    return C3D_OK;
+}
+
+extern "C" int c3d_read_tbl(const char* path, int32_t** ri, int32_t** rj, int32_t** rt10, int* R) {
+    if (!path || !ri || !rj || !rt10 || !R) return fail(C3D_ERR_INVALID, "c3d_read_tbl: null argument");
+    std::string txt;
+    if (!read_file(path, txt)) return fail(C3D_ERR_IO, std::string("cannot read ") + path);
+    std::vector<int32_t> vi, vj, vt;
+    size_t p = 0;
+    while (p < txt.size()) {
+        size_t e = txt.find('\n', p);
+        if (e == std::string::npos) e = txt.size();
+        std::string line = txt.substr(p, e - p);
+        p = e + 1;
+        for (char& c : line) if (c == '(' || c == ')') c = ' ';
+        // tokens: assign resid I and name ca resid J and name ca D DMINUS DPLUS
+        std::vector<std::string> tok;
+        size_t q = 0;
+        while (q < line.size()) {
+            while (q < line.size() && is_ws(line[q])) ++q;
+            size_t b = q;
+            while (q < line.size() && !is_ws(line[q])) ++q;
+            if (q > b) tok.push_back(line.substr(b, q - b));
+        }
+        if (tok.empty()) continue;
+        if (tok[0].compare(0, 6, "assign") != 0) return fail(C3D_ERR_IO, std::string("contact.tbl: unexpected row: ") + line);
+        if (tok.size() < 14) return fail(C3D_ERR_IO, std::string("contact.tbl: short row: ") + line);
+        vi.push_back(atoi(tok[2].c_str()));
+        vj.push_back(atoi(tok[7].c_str()));
+        vt.push_back((int32_t)llround(atof(tok[11].c_str()) * 10.0));
+    }
+    const size_t r = vi.size();
+    *ri = (int32_t*)malloc(sizeof(int32_t) * (r ? r : 1));
+    *rj = (int32_t*)malloc(sizeof(int32_t) * (r ? r : 1));
+    *rt10 = (int32_t*)malloc(sizeof(int32_t) * (r ? r : 1));
+    if (!*ri || !*rj || !*rt10) return fail(C3D_ERR_NOMEM, "out of memory");
+    for (size_t k = 0; k < r; ++k) { (*ri)[k] = vi[k]; (*rj)[k] = vj[k]; (*rt10)[k] = vt[k]; }
+    *R = (int)r;
+    return C3D_OK;
+}
+
+// Residue names carry no physics in the bead model; any of the 20 standard names keeps the
+// reference's reindex_chain / seq_chain (chromosome3D.pl:847, :225) happy.  The bundled
+// output_models use MET for every bead, so do we.
+extern "C" int c3d_write_pdb(const char* path, const float* xyz, int n, double e_noe, double e_bond, double e_rep,
+                             const char* title) {
+    if (!path || !xyz || n < 1) return fail(C3D_ERR_INVALID, "c3d_write_pdb: bad arguments");
+    FILE* f = fopen(path, "w");
+    if (!f) return fail(C3D_ERR_IO, std::string("cannot write ") + path);
+    fprintf(f, "REMARK FILENAME=\"%s\"\n", title ? title : path);
+    fprintf(f, "REMARK ===============================================================\n");
+    fprintf(f, "REMARK overall = %.4f\n", e_noe + e_bond + e_rep);
+    fprintf(f, "REMARK bon = %.4f\n", e_bond);
+    fprintf(f, "REMARK vdw = %.4f\n", e_rep);
+    fprintf(f, "REMARK noe = %.4f\n", e_noe);
+    fprintf(f, "REMARK ===============================================================\n");
+    for (int i = 0; i < n; ++i) {
+        const char* rn = "MET";
+        // cols: 1-6 ATOM, 7-11 serial, 13-16 name, 18-20 resName, 22 chain(blank), 23-26 resSeq, 31-54 xyz
+        fprintf(f, "ATOM  %5d  CA  %3s  %4d    %8.3f%8.3f%8.3f  1.00  0.00\n", (i + 1) % 100000, rn, (i + 1) % 10000,
+                (double)xyz[3 * i], (double)xyz[3 * i + 1], (double)xyz[3 * i + 2]);
+    }
+    for (int i = 1; i < n; ++i) fprintf(f, "CONECT%5d%5d\n", i, i + 1);
+    fprintf(f, "END\n");
+    fclose(f);
+    return C3D_OK;
+}
+
+extern "C" int c3d_read_pdb_ca(const char* path, float** xyz, int* n_out) {
+    if (!path || !xyz || !n_out) return fail(C3D_ERR_INVALID, "c3d_read_pdb_ca: null argument");
+    std::string txt;
+    if (!read_file(path, txt)) return fail(C3D_ERR_IO, std::string("cannot read ") + path);
+    std::vector<float> v;
+    size_t p = 0;
+    while (p < txt.size()) {
+        size_t e = txt.find('\n', p);
+        if (e == std::string::npos) e = txt.size();
+        const std::string line = txt.substr(p, e - p);
+        p = e + 1;
+        if (line.compare(0, 4, "ATOM") != 0 || line.size() < 54) continue;
+        std::string an = line.substr(12, 4);
+        an.erase(std::remove(an.begin(), an.end(), ' '), an.end());
+        if (an != "CA") continue;
+        v.push_back((float)atof(line.substr(30, 8).c_str()));
+        v.push_back((float)atof(line.substr(38, 8).c_str()));
+        v.push_back((float)atof(line.substr(46, 8).c_str()));
+    }
+    if (v.empty()) return fail(C3D_ERR_IO, std::string("no CA atoms in ") + path);
+    *xyz = (float*)malloc(sizeof(float) * v.size());
+    if (!*xyz) return fail(C3D_ERR_NOMEM, "out of memory");
+    memcpy(*xyz, v.data(), sizeof(float) * v.size());
+    *n_out = (int)(v.size() / 3);
+    return C3D_OK;
+}
+
+static double round_dec(double d, int digits) {  // sprintf "%.Nf" then numeric use
+    char b[64];
+    snprintf(b, sizeof b, "%.*f", digits, d);
+    return strtod(b, nullptr);
+}
+
+extern "C" int c3d_assess(const float* xyz, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10,
+                          double relax, int* satisfied, double* sum_dev) {
+    if (!xyz || (R > 0 && (!ri || !rj || !rt10))) return fail(C3D_ERR_INVALID, "c3d_assess: null argument");
+    // the Perl reads coordinates back from the %8.3f PDB text
+    std::vector<double> x((size_t)3 * n);
+    for (size_t k = 0; k < x.size(); ++k) x[k] = round_dec((double)xyz[k], 3);
+    int count = 0;
+    double sdev = 0;
+    for (int k = 0; k < R; ++k) {
+        const int i = ri[k] - 1, j = rj[k] - 1;
+        if (i < 0 || j < 0 || i >= n || j >= n) return fail(C3D_ERR_INVALID, "c3d_assess: restraint index out of range");
+        const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+        const double d = round_dec(sqrt(dx * dx + dy * dy + dz * dz), 3);
+        const double t = rt10[k] / 10.0;
+        if (d < t + 0.0 + relax) ++count;
+        if (d < t - 0.0 - relax) --count;
+        if (d > t + 0.0 + 0.2) sdev += d - (t + 0.0);
+        if (d < t - 0.0 - 0.2) sdev += (t - 0.0) - d;
+    }
+    if (satisfied) *satisfied = count;
+    if (sum_dev) *sum_dev = sdev;
+    return C3D_OK;
+}
+
+static void avg_ranks(const std::vector<double>& v, std::vector<double>& r) {
+    const size_t m = v.size();
+    std::vector<uint32_t> idx(m);
+    for (size_t k = 0; k < m; ++k) idx[k] = (uint32_t)k;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return v[a] < v[b]; });
+    r.resize(m);
+    size_t k = 0;
+    while (k < m) {
+        size_t e = k;
+        while (e + 1 < m && v[idx[e + 1]] == v[idx[k]]) ++e;
+        const double rank = 0.5 * ((double)k + (double)e) + 1.0;
+        for (size_t q = k; q <= e; ++q) r[idx[q]] = rank;
+        k = e + 1;
+    }
+}
+
+extern "C" int c3d_spearman_if_dist(const double* IF, const float* xyz, int n, int range, double* rho) {
+    if (!IF || !xyz || !rho || n < 2) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist: bad arguments");
+    std::vector<double> x((size_t)3 * n);
+    for (size_t k = 0; k < x.size(); ++k) x[k] = round_dec((double)xyz[k], 3);
+    std::vector<double> a, b;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            if (std::abs(i - j) < range) continue;
+            const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+            a.push_back(IF[(size_t)i * n + j]);
+            b.push_back(round_dec(sqrt(dx * dx + dy * dy + dz * dz), 3));
+        }
+    if (a.size() < 2) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist: range leaves no pairs");
+    std::vector<double> ra, rb;
+    avg_ranks(a, ra);
+    avg_ranks(b, rb);
+    double ma = 0, mb = 0;
+    const size_t m = a.size();
+    for (size_t k = 0; k < m; ++k) { ma += ra[k]; mb += rb[k]; }
+    ma /= m; mb /= m;
+    double sab = 0, saa = 0, sbb = 0;
+    for (size_t k = 0; k < m; ++k) {
+        sab += (ra[k] - ma) * (rb[k] - mb);
+        saa += (ra[k] - ma) * (ra[k] - ma);
+        sbb += (rb[k] - mb) * (rb[k] - mb);
+    }
+    *rho = sab / sqrt(saa * sbb);
+    return C3D_OK;
+}

@@ -1,0 +1,92 @@
+// c3d_internal.h — shared between the HIP kernels (c3d_device.hip) and the C-ABI host (c3d_api.cpp).
+// Not part of the public boundary (that is include/c3d.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace c3d {
+
+constexpr float kBoltz = 0.0019872f;  // kcal/mol/K (X-PLOR/CNS AKMA)
+constexpr float kAccel = 418.4f;      // kcal/mol/A/amu -> A/ps^2
+
+// rows of the pair matrix owned by one workgroup = kWaves * kRowsPerWave
+constexpr int kWaves = 4;
+constexpr int kRowsPerWave = 4;
+constexpr int kTileRows = kWaves * kRowsPerWave;
+constexpr int kBlock = kWaves * 64;
+
+// far-away coordinates for the padding beads j in [n, npad): no NOE (target -0.0f), no repel
+constexpr float kPadCoord = 1.0e4f;
+
+struct DevModel {
+    int n, npad, ntiles, nrep;
+    int noe_pot, ang_mode;
+    float rs, tail_c, tail_b;      // soft tail: dE/dD = tail_c - tail_b / D^2  (D > rs)
+    float k_bond2, b0;             // 2*k_bond
+    float k_ang2, a0;              // 2*k_ang
+    float acc;                     // kAccel / mass
+    float t_fac;                   // T = t_fac * sum(v^2):  mass / kAccel / (ndf * kBoltz)
+    float fbeta;
+    float inv_n;
+};
+
+struct DevStep {
+    int kind;        // 0 MD T-coupling, 1 MD velocity rescale, 2 FIRE step, 3 FIRE begin, 4 MD begin
+    float dt;
+    float w_all;     // weights * w
+    float w_noe;     // w_all * s_noe
+    float w_rep4;    // 4 * w_vdw * k_rep
+    float rep_r2;    // (repel_s * r0_rep)^2
+    float t_bath;
+};
+
+struct DevFire {
+    float dt_start, dt_max, f_inc, f_dec, alpha_start, f_alpha, max_step;
+    int n_min;
+};
+
+struct FireState {   // per replica, double buffered
+    float dt, alpha;
+    int npos, pad;
+};
+
+// All device pointers of one context.  Layouts (npad = n rounded up to 64):
+//   tgt   [n][npad]            encoded restraint target (see encode_target)
+//   X,V,F [2][nrep][3][npad]   SoA coordinates / velocities / forces, double buffered by step parity
+//   Vinit [nrep][3][npad]
+//   P     [2][nrep][ntiles][4] per-tile partial sums
+//   S     [2][nrep]            FIRE state
+struct DevBuffers {
+    float* tgt;
+    float* X[2];
+    float* V[2];
+    float* F[2];
+    float* Vinit;
+    float* P[2];
+    FireState* S[2];
+    double* E;      // [nrep][4]
+};
+
+// host-callable launchers (defined in c3d_device.hip)
+hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int parity,
+                       bool general_tail, hipStream_t s);
+hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float* Fout,
+                              bool general_tail, hipStream_t s);
+hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe,
+                         float k_rep, int min_sep_unused, hipStream_t s);
+hipError_t launch_centre(const DevModel& m, const DevBuffers& b, int parity, hipStream_t s);
+// K1: IF (n*n fp64, device) -> dist10 (n*n int32, device) and encoded targets (n*npad, device)
+hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, double K, int min_sep, int rep_sep,
+                               double* scratchP, double* partial, int npartial, int32_t* dist10, float* tgt,
+                               hipStream_t s);
+
+// Target encoding shared by host (c3d_set_restraints) and device (K1):
+//   |v| = NOE target in Angstrom (0 = no restraint); sign bit set = repel disabled for the pair.
+inline float encode_target_host(float t, bool repel_on) {
+    union { float f; uint32_t u; } c;
+    c.f = t > 0 ? t : 0.0f;
+    if (!repel_on) c.u |= 0x80000000u;
+    return c.f;
+}
+
+}  // namespace c3d

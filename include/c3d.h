@@ -1,0 +1,163 @@
+/*
+ * c3d.h — C ABI of libc3d.so, the MI355X (gfx950) solver that replaces the
+ * `cns_solve < dgsa.inp` process the reference shells out to.
+ *
+ * Reference boundary being replaced (file:line under the reference tree):
+ *   chromosome3D.pl:87-89    IF2dist_new / dist2rr / carr2tbl  -> c3d_set_if_matrix,
+ *                            c3d_get_dist10, c3d_write_front_half
+ *   chromosome3D.pl:254-289  build_models: job.sh -> `cns_solve < dgsa.inp`, success iff
+ *                            <ID>_<M>.pdb exists                -> c3d_run / c3d_write_models
+ *   chromosome3D.pl:882-1846 the dgsa.inp deck (knobs :1093-1126, protocol :1574-1829)
+ *                                                               -> c3d_model / c3d_stage
+ *   chromosome3D.pl:769-829  assess_dgsa (rank by int(REMARK noe)) -> c3d_rank, c3d_assess
+ *   spearman_IF_pdb.pl:26-70 scoring                            -> c3d_spearman_if_dist
+ *
+ * Conventions: plain C types only; every function returns C3D_OK (0) or a negative
+ * c3d_status; c3d_last_error() gives a thread-local message.  The caller owns all host
+ * buffers, the library owns all device memory.  Nothing here falls back to a CPU solver:
+ * without a usable HIP device c3d_create fails with C3D_ERR_NO_DEVICE.
+ */
+#ifndef C3D_H_
+#define C3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    C3D_OK = 0,
+    C3D_ERR_INVALID = -1,    /* bad argument / call order */
+    C3D_ERR_NO_DEVICE = -2,  /* no HIP device, or the gfx950 code object cannot load */
+    C3D_ERR_HIP = -3,        /* a HIP runtime call failed */
+    C3D_ERR_IO = -4,         /* file could not be read / written / parsed */
+    C3D_ERR_NOMEM = -5
+} c3d_status;
+
+typedef struct c3d_ctx c3d_ctx;
+
+/* Energy model of one bead chain (defaults: c3d_default_model).  Mirrors the deck:
+ * con_wt chromosome3D.pl:66,1111,1120; mass/fbeta :1415-1416; SEPARATION :20. */
+typedef struct {
+    int32_t min_sep;   /* 5: restraints only for |i-j| >= min_sep                        */
+    int32_t noe_pot;   /* 0 symmetric soft-square, 1 X-PLOR soft-square (default), 2 square */
+    int32_t rep_sep;   /* repel acts on |i-j| >= rep_sep                                 */
+    int32_t ang_mode;  /* (i,i+2) term: 0 lower bound only, 1 harmonic                   */
+    float s_noe;       /* NOE scale = con_wt = 10                                        */
+    float rswitch;     /* 1.0                                                            */
+    float asym;        /* 2.0 asymptote slope                                            */
+    float k_bond, b0;  /* pseudo-bond (i,i+1)                                            */
+    float k_ang, a0;   /* pseudo-angle (i,i+2)                                           */
+    float r0_rep;      /* bead contact distance, scaled by stage `repel`                 */
+    float k_rep;       /* bead-level repel multiplier                                    */
+    float mass;        /* 100 amu                                                        */
+    float fbeta;       /* 10 /ps                                                         */
+} c3d_model;
+
+/* One stage of the annealing schedule (defaults: c3d_default_schedule, which restates
+ * chromosome3D.pl:1631-1700 hot stages, :1729-1782 slow cool, :1790-1803 minimisation). */
+typedef struct {
+    int32_t kind;      /* 0 MD + T-coupling, 1 MD + velocity rescale, 2 FIRE minimise    */
+    int32_t nsteps;
+    float dt;          /* ps (MD)                                                        */
+    float w_all;       /* `weights * w`                                                  */
+    float w_vdw;       /* vdw weight                                                     */
+    float repel_s;     /* nbonds repel=                                                  */
+    float t_bath;      /* K                                                              */
+} c3d_stage;
+
+typedef struct {
+    float dt_start, dt_max, f_inc, f_dec, alpha_start, f_alpha, max_step;
+    int32_t n_min;
+} c3d_fire_params;
+
+/* --- lifecycle ---------------------------------------------------------------------- */
+const char* c3d_last_error(void);
+const char* c3d_version(void);
+int c3d_device_count(void);
+int c3d_create(int device, c3d_ctx** out);
+void c3d_destroy(c3d_ctx* ctx);
+
+void c3d_default_model(c3d_model* m);
+void c3d_default_fire(c3d_fire_params* f);
+/* Fills up to `cap` stages; returns the number of stages of the default schedule
+ * (1 pre-minimisation + 5 hot + 81 cool + 1 final minimisation of `min_steps`). */
+int c3d_default_schedule(c3d_stage* stages, int cap, int min_steps);
+
+/* --- problem set-up ----------------------------------------------------------------- */
+/* K1 on device: D = K * mean(IF^alpha) / IF^alpha, quantised like "%.1f"; builds the n x n
+ * target matrix (restraints for |i-j| >= min_sep, IF > 0).  IF is row-major n*n (host). */
+int c3d_set_if_matrix(c3d_ctx* ctx, const double* IF, int n, double alpha, double K);
+/* Alternative entry: restraint rows as in contact.tbl (1-based i, j; target in tenths of A). */
+int c3d_set_restraints(c3d_ctx* ctx, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10);
+/* n*n int32, tenths of an Angstrom, -10 where IF == 0 (the <ID>.dist content). */
+int c3d_get_dist10(c3d_ctx* ctx, int32_t* dist10);
+int c3d_num_beads(const c3d_ctx* ctx);
+int c3d_num_restraints(const c3d_ctx* ctx);
+
+int c3d_set_model(c3d_ctx* ctx, const c3d_model* m);
+int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const c3d_fire_params* fire,
+                     float gtol, int check_every);
+/* use_graph != 0: replay the step sequence from hipGraphs (default 1). */
+int c3d_set_option(c3d_ctx* ctx, const char* key, double value);
+
+/* --- replicas ----------------------------------------------------------------------- */
+/* n_replicas chains with ids first_replica .. first_replica+n_replicas-1; the RNG is
+ * Philox4x32-10 keyed by (seed, replica id), so a replica's trajectory does not depend on
+ * how replicas are spread over processes or GPUs (seed 82364: chromosome3D.pl:980). */
+int c3d_init_replicas(c3d_ctx* ctx, int n_replicas, uint64_t seed, uint32_t first_replica);
+/* overwrite coordinates (n_replicas*n*3, xyz interleaved) — tests and restarts */
+int c3d_set_coords(c3d_ctx* ctx, const float* xyz);
+int c3d_get_coords(c3d_ctx* ctx, float* xyz);
+int c3d_get_velocities(c3d_ctx* ctx, float* v);
+
+/* --- solve -------------------------------------------------------------------------- */
+/* whole schedule, with the gtol exit of the final minimisation; centres the models. */
+int c3d_run(c3d_ctx* ctx);
+/* advance by at most nsteps SA steps of the schedule (no early exit); returns steps done
+ * through *done.  Used by the benchmark and by tests that follow a trajectory. */
+int c3d_run_steps(c3d_ctx* ctx, long nsteps, long* done);
+long c3d_schedule_length(const c3d_ctx* ctx);   /* SA steps in the whole schedule */
+long c3d_steps_done(const c3d_ctx* ctx);
+int c3d_centre(c3d_ctx* ctx);
+/* device time of the last c3d_run / c3d_run_steps, from HIP events on the solver's stream */
+int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* launches);
+
+/* One evaluation through the production pair kernel at the replicas' current coordinates:
+ * F (n_replicas*n*3) = total weighted force; e (n_replicas*3) = unweighted (noe, bond+angle,
+ * repel) energies in fp64. Either may be NULL. */
+int c3d_eval(c3d_ctx* ctx, float w_all, float w_vdw, float repel_s, float* F, double* e);
+/* per replica: e[3*r + {0,1,2}] = E_noe, E_bond(+angle), E_repel at the final weights */
+int c3d_get_energies(c3d_ctx* ctx, double* e);
+/* rank[k] = replica index with the k-th lowest int(E_noe) (chromosome3D.pl:796-802,822-828);
+ * ties broken by replica id. */
+int c3d_rank(c3d_ctx* ctx, int32_t* rank);
+
+/* --- host helpers (formats of the reference; no device needed) ------------------------ */
+/* chromosome3D.pl:116-129,164-179: whitespace-separated numbers, N = fields on line 1.
+ * *IF is malloc'ed (free with c3d_free). */
+int c3d_parse_if_file(const char* path, double** IF, int* n);
+void c3d_free(void* p);
+/* <ID>.dist, <ID>.rr, contact.tbl exactly as chromosome3D.pl:156-161, 203-205, 360 write them */
+int c3d_write_front_half(const int32_t* dist10, int n, int min_sep, const char* dist_path,
+                         const char* rr_path, const char* tbl_path, int* n_restraints);
+/* contact.tbl reader (format chromosome3D.pl:360; parse rules :497-520) */
+int c3d_read_tbl(const char* path, int32_t** ri, int32_t** rj, int32_t** rt10, int* R);
+/* CA-only model in the layout assess_dgsa leaves (chromosome3D.pl:853-857, 208-215) preceded
+ * by REMARK lines carrying the energies (`REMARK noe = ...`, :611-614). resname from the
+ * bundled output_models (MET). */
+int c3d_write_pdb(const char* path, const float* xyz, int n, double e_noe, double e_bond, double e_rep,
+                  const char* title);
+int c3d_read_pdb_ca(const char* path, float** xyz, int* n);
+/* chromosome3D.pl:447-485, 581-600 on coordinates rounded to 3 decimals as a PDB holds them */
+int c3d_assess(const float* xyz, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10,
+               double relax, int* satisfied, double* sum_dev);
+/* spearman_IF_pdb.pl:42-70 */
+int c3d_spearman_if_dist(const double* IF, const float* xyz, int n, int range, double* rho);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C3D_H_ */

@@ -1,0 +1,125 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/c3d.h declares,
+refuses to run without a GPU, and its host-format helpers reproduce the reference's files."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.util import GOLD, golden, load_if, load_pdb_xyz, model_pdb, write_if_text, REF_SPEARMAN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = golden()
+
+
+def test_library_exports_every_declared_symbol(built):
+    from chromosome3d_amd import lib
+    L = lib.load()
+    hdr = open(os.path.join(ROOT, "include", "c3d.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(c3d_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/c3d.h but not exported"
+    assert declared == set(lib.SIGNATURES), "python binding table out of sync with include/c3d.h"
+
+
+def test_no_gpu_fails_loudly(built):
+    """Without a device the product path must raise, never fall back to a CPU solver."""
+    from chromosome3d_amd import lib
+    L = lib.load()
+    if L.c3d_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    rc = L.c3d_create(0, C.byref(h))
+    assert rc == -2 and b"no HIP device" in L.c3d_last_error()
+    from chromosome3d_amd import Solver, C3DError
+    with pytest.raises(C3DError):
+        Solver(0)
+
+
+def test_product_never_touches_oracle():
+    """The oracle is test infrastructure: nothing under chromosome3d_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "chromosome3d_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".pl", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and False, f"{f} mentions the oracle"
+
+
+@pytest.mark.parametrize("cid", ["chr21_1mb", "chr22_1mb", "chr13_1mb", "chr1_500kb"])
+def test_host_writers_reproduce_reference_files(built, cid, tmp_path):
+    """c3d_write_front_half (dist2rr + carr2tbl formats, chromosome3D.pl:156-161,203-205,360)."""
+    from chromosome3d_amd import pipeline
+    from oracle import oracle as O
+    d10 = O.if_to_dist10(load_if(cid))          # the K1 result is checked on the GPU; formats here
+    n = pipeline.write_front_half(d10, str(tmp_path), cid)
+    assert n == G[cid]["restraints"]
+    md5 = lambda p: hashlib.md5(open(p, "rb").read()).hexdigest()
+    assert md5(tmp_path / "contact.tbl") == G[cid]["md5_tbl"]
+    assert md5(tmp_path / f"{cid}.dist") == G[cid]["md5_dist"]
+    assert md5(tmp_path / f"{cid}.rr") == G[cid]["md5_rr"]
+    ri, rj, rt = pipeline.read_tbl(str(tmp_path / "contact.tbl"))
+    oi, oj, ot = O.dist_to_rr(d10)
+    assert np.array_equal(ri, oi) and np.array_equal(rj, oj) and np.array_equal(rt, ot)
+
+
+def test_host_parser_accepts_reference_text_format(built, tmp_path):
+    from chromosome3d_amd import pipeline
+    p = os.path.join(GOLD, "inputs", "chr21_1mb_matrix.txt")
+    m = pipeline.parse_if_file(p)
+    assert np.array_equal(m, load_if("chr21_1mb")) and pipeline.calc_len_IF(p) == 37
+    # tabs / multiple blanks / LF-only / leading blanks are all accepted (split /\s+/, :118-126)
+    IF = load_if("chr22_1mb")
+    q = tmp_path / "m.txt"
+    with open(q, "w") as fh:
+        for row in IF:
+            fh.write("  " + "\t ".join(repr(float(v)) for v in row) + "\n")
+    assert np.array_equal(pipeline.parse_if_file(str(q)), IF)
+    # ragged / empty input -> error, not a crash
+    from chromosome3d_amd import C3DError
+    (tmp_path / "bad.txt").write_text("1 2 3\n4 5\n")
+    with pytest.raises(C3DError):
+        pipeline.parse_if_file(str(tmp_path / "bad.txt"))
+    (tmp_path / "empty.txt").write_text("")
+    with pytest.raises(C3DError):
+        pipeline.parse_if_file(str(tmp_path / "empty.txt"))
+    with pytest.raises(C3DError):
+        pipeline.parse_if_file(str(tmp_path / "missing.txt"))
+
+
+@pytest.mark.parametrize("cid", sorted(G))
+def test_host_assessment_and_spearman(built, cid):
+    from chromosome3d_amd import pipeline
+    from oracle import oracle as O
+    IF = load_if(cid)
+    rows = O.dist_to_rr(O.if_to_dist10(IF))
+    X = load_pdb_xyz(model_pdb(cid))
+    sat, dev = pipeline.assess(X, rows)
+    assert f"{sat}/{len(rows[0])}" == G[cid]["satisfied"] and "%.2f" % dev == "%.2f" % G[cid]["sum_dev"]
+    assert abs(pipeline.spearman_IF_pdb(IF, X) - REF_SPEARMAN[cid]) < 5e-5
+    assert pipeline.spearman_IF_pdb(IF, X) == pytest.approx(O.spearman_if_dist(IF, X, 3), abs=1e-12)
+
+
+def test_pdb_roundtrip_and_layout(built, tmp_path):
+    """Output layout the reference's Perl post-processing expects (parse_pdb_row :674-691,
+    get_cns_energy :602-618, add_connect_rows :208-215)."""
+    from chromosome3d_amd import pipeline
+    x = (np.random.default_rng(1).normal(size=(41, 3)) * 30).astype(np.float32)
+    p = tmp_path / "m.pdb"
+    pipeline.write_pdb(str(p), x, 12345.678, 10.0, 2.5, title="t_1.pdb")
+    lines = open(p).read().splitlines()
+    noe = [l for l in lines if l.startswith("REMARK noe")]
+    assert len(noe) == 1 and int(float(noe[0].replace(" ", "").split("=")[1])) == 12345
+    atoms = [l for l in lines if l.startswith("ATOM")]
+    assert len(atoms) == 41
+    a = atoms[6]
+    assert a[12:16].strip() == "CA" and a[17:20] == "MET" and a[21] == " " and int(a[22:27]) == 7 and int(a[6:11]) == 7
+    assert abs(float(a[30:38]) - round(float(x[6, 0]), 3)) < 1e-6
+    assert [l for l in lines if l.startswith("CONECT")][0] == "CONECT    1    2"
+    assert len([l for l in lines if l.startswith("CONECT")]) == 40 and lines[-1] == "END"
+    y = pipeline.read_pdb_ca(str(p))
+    assert np.allclose(y, np.round(x.astype(np.float64), 3), atol=1e-3)

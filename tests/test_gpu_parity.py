@@ -1,0 +1,288 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on identical inputs.
+
+Tolerances (fp32 device arithmetic vs fp64 oracle):
+  K1 target distances          bit-exact (integers, tenths of an Angstrom)
+  forces                       |dF| <= 2e-4 |F| + 2e-5 max|F|   per component
+  energies (fp64 on device)    relative 1e-6
+  short trajectories           coordinates within 2e-3 A after 20 MD / 30 FIRE steps
+  full schedule                statistical: Spearman / final energy vs the oracle's replicas
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests.util import (REF_SPEARMAN, golden, load_if, oracle_fire_from, oracle_model_from, random_coil)
+
+pytestmark = pytest.mark.gpu
+G = golden()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+# ---------------------------------------------------------------------------------------------
+# K1: IF -> target distance
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cid", sorted(G) + ["chr21_500kb"])
+def test_k1_bit_exact_and_front_half_files(solver, O, cid, tmp_path):
+    from chromosome3d_amd import pipeline
+    IF = load_if(cid)
+    d10 = pipeline.IF2dist_new(solver, IF)
+    assert np.array_equal(d10, O.if_to_dist10(IF))
+    if cid in G:
+        n = pipeline.write_front_half(d10, str(tmp_path), cid)
+        assert n == G[cid]["restraints"] == solver.num_restraints
+        assert hashlib.md5(open(tmp_path / "contact.tbl", "rb").read()).hexdigest() == G[cid]["md5_tbl"]
+        assert hashlib.md5(open(tmp_path / f"{cid}.dist", "rb").read()).hexdigest() == G[cid]["md5_dist"]
+
+
+@pytest.mark.parametrize("K,alpha", [(11, 0.5), (7, 1.0), (20, 0.3), (11, 0.75)])
+def test_k1_option_sweep(solver, O, K, alpha):
+    """-k / -a options (chromosome3D.pl:31-32)."""
+    from chromosome3d_amd import pipeline
+    IF = load_if("chr20_1mb")
+    assert np.array_equal(pipeline.IF2dist_new(solver, IF, K, alpha), O.if_to_dist10(IF, alpha, K))
+
+
+def test_k1_synthetic_edge_cases(solver, O):
+    from chromosome3d_amd import pipeline
+    rng = np.random.default_rng(7)
+    for n in (2, 5, 63, 64, 65, 130):
+        A = rng.lognormal(3.0, 2.0, size=(n, n))
+        IF = A + A.T
+        IF[rng.random((n, n)) < 0.1] = 0.0          # zeros -> -1 sentinel
+        IF = np.minimum(IF, IF.T)
+        np.fill_diagonal(IF, IF.max() * 10)
+        d = pipeline.IF2dist_new(solver, IF)
+        assert np.array_equal(d, O.if_to_dist10(IF)), n
+    # exact decimal ties: D = K / (P / mean) hitting x.x5 exactly, rounds half-to-even like printf
+    IF = np.array([[16.0, 4.0], [4.0, 16.0]])   # P = 4,2,2,4 mean 3 -> D = 11*3/4 = 8.25, 11*3/2 = 16.5
+    assert np.array_equal(pipeline.IF2dist_new(solver, IF), O.if_to_dist10(IF))
+
+
+# ---------------------------------------------------------------------------------------------
+# K2: restraint energy / force through the production pair kernel
+# ---------------------------------------------------------------------------------------------
+def _force_close(F, Fo):
+    scale = np.abs(Fo).max()
+    return np.abs(F - Fo) <= 2e-4 * np.abs(Fo) + 2e-5 * scale
+
+
+@pytest.mark.parametrize("cid", ["chr21_1mb", "chr13_1mb", "chr1_500kb"])
+@pytest.mark.parametrize("pot", [0, 1, 2])
+def test_force_energy_parity(solver, O, cid, pot):
+    from chromosome3d_amd import default_model, pipeline
+    IF = load_if(cid)
+    n = IF.shape[0]
+    d10 = pipeline.IF2dist_new(solver, IF)
+    m = default_model(noe_pot=pot)
+    solver.set_model(m)
+    nrep = 3
+    solver.init_replicas(nrep, 1234, 5)
+    x = np.stack([random_coil(n, 100 + r) * s for r, s in zip(range(nrep), (1.0, 0.4, 0.15))])
+    solver.set_coords(x)
+    om = oracle_model_from(m, n)
+    for (w, wv, rs) in [(1.0, 1.0, 0.85), (0.1, 20.0, 0.5), (0.4, 0.003, 0.9)]:
+        F, e = solver.eval(w, wv, rs)
+        for r in range(nrep):
+            Fo, eo = O.energy_force(om, d10, x[r].astype(np.float64), w, wv, rs)
+            assert _force_close(F[r], Fo).all(), (cid, pot, w, np.abs(F[r] - Fo).max(), np.abs(Fo).max())
+            assert np.allclose(e[r], eo, rtol=1e-6, atol=1e-6)
+
+
+def test_force_parity_general_tail_and_lower_bound_angle(solver, O):
+    """asymptote != 2 rswitch takes the general-tail kernel; ang_mode 0 is the lower-bound form."""
+    from chromosome3d_amd import default_model, pipeline
+    IF = load_if("chr20_1mb")
+    n = IF.shape[0]
+    d10 = pipeline.IF2dist_new(solver, IF)
+    for kw in (dict(noe_pot=1, asym=1.0, rswitch=0.5), dict(noe_pot=0, asym=3.0, rswitch=2.0),
+               dict(noe_pot=1, ang_mode=0, k_ang=200.0, a0=6.0), dict(noe_pot=1, k_ang=0.0)):
+        m = default_model(**kw)
+        solver.set_model(m)
+        solver.init_replicas(2, 1, 0)
+        x = np.stack([random_coil(n, 7) * 0.5, random_coil(n, 8) * 0.2])
+        solver.set_coords(x)
+        F, e = solver.eval(0.7, 2.0, 0.9)
+        om = oracle_model_from(m, n)
+        for r in range(2):
+            Fo, eo = O.energy_force(om, d10, x[r].astype(np.float64), 0.7, 2.0, 0.9)
+            assert _force_close(F[r], Fo).all(), kw
+            assert np.allclose(e[r], eo, rtol=1e-6), kw
+
+
+def test_restraint_entry_equals_matrix_entry(solver, O):
+    """c3d_set_restraints (the contact.tbl boundary) builds the same problem as c3d_set_if_matrix."""
+    from chromosome3d_amd import default_model, pipeline
+    IF = load_if("chr22_1mb")
+    n = IF.shape[0]
+    solver.set_model(default_model())
+    d10 = pipeline.IF2dist_new(solver, IF)
+    solver.init_replicas(2, 9, 0)
+    x = np.stack([random_coil(n, 1), random_coil(n, 2) * 0.3])
+    solver.set_coords(x)
+    Fa, ea = solver.eval(1.0, 1.0, 0.85)
+    ri, rj, rt = O.dist_to_rr(d10)
+    solver.set_restraints(n, ri, rj, rt)
+    assert solver.num_restraints == len(ri)
+    solver.init_replicas(2, 9, 0)
+    solver.set_coords(x)
+    Fb, eb = solver.eval(1.0, 1.0, 0.85)
+    assert np.array_equal(Fa, Fb) and np.array_equal(ea, eb)
+
+
+def test_physical_invariants_full_size(solver):
+    """Size-independent properties at the benchmark size (chr1_500kb, 20 replicas): Newton's third
+    law (net force ~ 0), rigid-motion invariance of energies, replica independence."""
+    from chromosome3d_amd import default_model, pipeline
+    IF = load_if("chr1_500kb")
+    n = IF.shape[0]
+    solver.set_model(default_model())
+    pipeline.IF2dist_new(solver, IF)
+    solver.init_replicas(20, 82364, 0)
+    x = solver.coords()
+    F, e = solver.eval(1.0, 1.0, 0.85)
+    assert np.isfinite(F).all() and np.isfinite(e).all()
+    net = np.abs(F.sum(1)).max(1)
+    assert (net < 2e-5 * np.abs(F).sum(1).max(1)).all()
+    # rotate + translate every replica: energies unchanged (fp32 coordinates -> 1e-5 relative)
+    c, s = np.cos(0.7), np.sin(0.7)
+    Rm = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float32)
+    solver.set_coords(x @ Rm.T + np.float32([3.0, -2.0, 1.0]))
+    _, e2 = solver.eval(1.0, 1.0, 0.85)
+    assert np.allclose(e, e2, rtol=2e-5)
+    # a replica's numbers do not depend on which batch it sits in
+    solver.init_replicas(4, 82364, 7)
+    x4 = solver.coords()
+    assert np.array_equal(x4, x[7:11])
+    F4, e4 = solver.eval(1.0, 1.0, 0.85)
+    assert np.array_equal(F4, F[7:11]) and np.array_equal(e4, e[7:11])
+
+
+# ---------------------------------------------------------------------------------------------
+# K3/K4: integrators
+# ---------------------------------------------------------------------------------------------
+def _setup(solver, cid, stages, nrep=2, seed=82364, **model_kw):
+    from chromosome3d_amd import default_fire, default_model, make_stages, pipeline
+    IF = load_if(cid)
+    m = default_model(**model_kw)
+    solver.set_model(m)
+    d10 = pipeline.IF2dist_new(solver, IF)
+    fire = default_fire()
+    solver.set_schedule(make_stages(stages), fire)
+    solver.init_replicas(nrep, seed, 0)
+    return IF, d10, m, fire
+
+
+def test_initial_state_matches_oracle_rng(solver, O):
+    IF, d10, m, fire = _setup(solver, "chr21_1mb", [(0, 1, 0.003, 1.0, 1.0, 0.9, 2000.0)], nrep=3)
+    om = oracle_model_from(m, IF.shape[0])
+    x = solver.coords()
+    for r in range(3):
+        assert np.allclose(x[r], O.init_coords(om, 82364, r), atol=2e-5)
+    solver.run_steps(0)
+
+
+@pytest.mark.parametrize("cid", ["chr21_1mb", "chr13_1mb"])
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_md_short_trajectory(solver, O, cid, use_graph):
+    stages = [(0, 12, 0.003, 0.4, 0.003, 0.9, 2000.0), (1, 8, 0.005, 1.0, 0.05, 1.0, 1500.0)]
+    IF, d10, m, fire = _setup(solver, cid, stages)
+    solver.set_option("use_graph", use_graph)
+    x0 = solver.coords()
+    done = solver.run_steps(10 ** 6)
+    assert done == 20 == solver.schedule_length
+    x, v = solver.coords(), solver.velocities()
+    om, of = oracle_model_from(m, IF.shape[0]), oracle_fire_from(fire)
+    for r in range(2):
+        xo, vo, ev = O.run_schedule(om, d10, O.make_stages(stages), of, 82364, r, x0=x0[r].astype(np.float64))
+        # run_schedule centres at the end; compare centred coordinates
+        xc = x[r].astype(np.float64)
+        xc -= xc.mean(0)
+        assert ev == 20
+        assert np.abs(xc - xo).max() < 2e-3, np.abs(xc - xo).max()
+        assert np.abs(v[r] - vo).max() < 2e-3 * max(1.0, np.abs(vo).max())
+    solver.set_option("use_graph", 1)
+
+
+@pytest.mark.parametrize("cid", ["chr21_1mb", "chr20_1mb"])
+def test_fire_short_trajectory(solver, O, cid):
+    stages = [(2, 30, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    IF, d10, m, fire = _setup(solver, cid, stages)
+    x0 = solver.coords()
+    assert solver.run_steps(10 ** 6) == 31      # FIRE begin evaluation + 30 steps
+    x = solver.coords()
+    om, of = oracle_model_from(m, IF.shape[0]), oracle_fire_from(fire)
+    for r in range(2):
+        xo, _, ev = O.run_schedule(om, d10, O.make_stages(stages), of, 82364, r, x0=x0[r].astype(np.float64))
+        xc = x[r].astype(np.float64)
+        xc -= xc.mean(0)
+        assert ev == 31
+        assert np.abs(xc - xo).max() < 2e-3, np.abs(xc - xo).max()
+
+
+def test_graph_replay_is_bitwise_eager(solver):
+    from chromosome3d_amd import default_schedule
+    stages = [(2, 40, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 60, 0.003, 0.2, 20.0, 0.5, 2000.0), (1, 24, 0.005, 1.0, 0.01, 1.0, 1900.0),
+              (2, 100, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    out = []
+    for g in (0, 1, 1):
+        _setup(solver, "chr20_1mb", stages, nrep=5)
+        solver.set_option("use_graph", g)
+        solver.set_option("graph_chunk", 32)
+        solver.run()
+        out.append((solver.coords(), solver.energies()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[1][0], out[2][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    solver.set_option("graph_chunk", 256)
+    assert len(default_schedule()) == 88
+
+
+def test_minimiser_reaches_a_stationary_point_and_energy_drops(solver):
+    stages = [(2, 3000, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    _setup(solver, "chr13_1mb", stages, nrep=4)
+    e0 = solver.energies()
+    solver.set_schedule(__import__("chromosome3d_amd").make_stages(stages), None, 1e-3, 250)
+    solver.init_replicas(4, 82364, 0)
+    solver.run()
+    e1 = solver.energies()
+    F, _ = solver.eval(1.0, 1.0, 0.85)
+    assert (e1.sum(1) < 0.2 * e0.sum(1)).all()
+    assert np.sqrt((F.astype(np.float64) ** 2).mean(axis=(1, 2))).max() < 5e-3
+    assert solver.steps_done < 3001            # gtol exit fired
+    x = solver.coords()
+    assert np.abs(x.mean(1)).max() < 1e-3      # centred (deck :1806-1816)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole schedule: statistical parity (device vs oracle, and vs the bundled reference model)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cid,tol_ref", [("chr21_1mb", 0.02), ("chr13_1mb", 0.02), ("chr19_500kb", 0.02)])
+def test_full_schedule_statistics(solver, O, cid, tol_ref):
+    from chromosome3d_amd import default_fire, default_model, default_schedule, pipeline
+    IF = load_if(cid)
+    s = solver
+    d10 = pipeline.IF2dist_new(s, IF)
+    xyz, en = pipeline.build_models(s, model_count=8, gtol=0.0)
+    rho = np.array([pipeline.spearman_IF_pdb(IF, xyz[r]) for r in range(8)])
+    best = int(np.argmin(en[:, 0].astype(np.int64)))
+    # against the oracle running the same schedule (chaotic trajectories: compare distributions)
+    m, fire = default_model(), default_fire()
+    om, of = oracle_model_from(m, IF.shape[0]), oracle_fire_from(fire)
+    st = default_schedule()
+    orows = [(x.kind, x.nsteps, x.dt, x.w_all, x.w_vdw, x.repel_s, x.t_bath) for x in st]
+    rho_o, e_o = [], []
+    for r in range(3):
+        xo, _, _ = O.run_schedule(om, d10, O.make_stages(orows), of, 82364, r)
+        rho_o.append(O.spearman_if_dist(IF, xo, 3))
+        e_o.append(O.energy_force(om, d10, xo, 1, 1, 0.85)[1][0])
+    assert abs(rho.mean() - np.mean(rho_o)) < 0.01, (rho, rho_o)
+    assert abs(np.median(en[:, 0]) / np.median(e_o) - 1.0) < 0.03, (en[:, 0], e_o)
+    # against the bundled reference model: Spearman of the best-ranked replica
+    assert abs(rho[best] - REF_SPEARMAN[cid]) < tol_ref, (rho[best], REF_SPEARMAN[cid])
+    order = s.rank()
+    assert order[0] == best or int(en[order[0], 0]) == int(en[best, 0])

@@ -1,0 +1,72 @@
+"""Shared helpers of the test-suite (fixtures live in tests/golden)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+# Spearman(IF, d) of the bundled reference models
+REF_SPEARMAN = {"chr21_1mb": -0.8447, "chr22_1mb": -0.7393, "chr20_1mb": -0.8353, "chr13_1mb": -0.9152,
+                "chr19_500kb": -0.8311, "chr4_1mb": -0.9488, "chr1_500kb": -0.8722, "chr21_500kb": -0.9090}
+
+
+def golden():
+    with open(os.path.join(GOLD, "front_half_golden.json")) as fh:
+        return json.load(fh)
+
+
+def load_if(cid):
+    """IF matrix of a bundled chromosome as float64 (verbatim text or packed upper triangle)."""
+    p = os.path.join(GOLD, "inputs", f"{cid}_matrix.txt")
+    if os.path.exists(p):
+        rows = [[float(t) for t in line.split()] for line in open(p) if line.strip()]
+        return np.array(rows, dtype=np.float64)
+    z = np.load(os.path.join(GOLD, "inputs", f"{cid}_upper.npz"))
+    n = int(z["n"])
+    m = np.zeros((n, n))
+    iu = np.triu_indices(n)
+    m[iu] = z["upper"]
+    m.T[iu] = z["upper"]
+    return m
+
+
+def write_if_text(IF, path, crlf=True):
+    """Text file in the bundled format: numbers separated by single spaces, lines end ' \\r\\n'."""
+    with open(path, "w", newline="") as fh:
+        for row in IF:
+            fh.write(" ".join(repr(float(v)) for v in row) + (" \r\n" if crlf else "\n"))
+
+
+def model_pdb(cid):
+    return glob.glob(os.path.join(GOLD, "models", f"{cid}_rank*_a11.pdb"))[0]
+
+
+def load_pdb_xyz(path):
+    return np.array([[float(l[30:38]), float(l[38:46]), float(l[46:54])] for l in open(path) if l.startswith("ATOM")])
+
+
+def oracle_model_from(m, n):
+    """oracle Model (fp64) holding exactly the float32 parameter values of a c3d_model."""
+    from oracle import oracle as O
+    return O.default_model(n, min_sep=m.min_sep, noe_pot=m.noe_pot, rep_sep=m.rep_sep, ang_mode=m.ang_mode,
+                           s_noe=float(m.s_noe), rswitch=float(m.rswitch), asym=float(m.asym),
+                           k_bond=float(m.k_bond), b0=float(m.b0), k_ang=float(m.k_ang), a0=float(m.a0),
+                           r0_rep=float(m.r0_rep), k_rep=float(m.k_rep), mass=float(m.mass), fbeta=float(m.fbeta))
+
+
+def oracle_fire_from(f):
+    from oracle import oracle as O
+    return O.default_fire(dt_start=float(f.dt_start), dt_max=float(f.dt_max), f_inc=float(f.f_inc),
+                          f_dec=float(f.f_dec), alpha_start=float(f.alpha_start), f_alpha=float(f.f_alpha),
+                          max_step=float(f.max_step), n_min=int(f.n_min))
+
+
+def random_coil(n, seed, step=3.8):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    x = np.cumsum(step * d, axis=0)
+    return (x - x.mean(0)).astype(np.float32)
