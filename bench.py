@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
+    ap.add_argument("--rpw", type=int, default=0, help="rows per wave of the step kernel (tuning knob; 0 = library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,6 +99,8 @@ def main():
     R = s.num_restraints
     s.set_schedule(stages, fire, 0.0, 250)       # gtol 0: fixed-length schedule (no early exit)
     s.set_option("use_graph", 0 if args.no_graph else 1)
+    if args.rpw:
+        s.set_option("rows_per_wave", args.rpw)
     L = s.schedule_length
 
     def sync_all():

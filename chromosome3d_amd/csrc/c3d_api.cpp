@@ -82,6 +82,8 @@ struct c3d_ctx {
     float gtol = 0.0f;
     int check_every = 250;
     bool use_graph = true;
+    int rpw = 2;
+    int stage_dma = 1;
     int graph_chunk = 256;
 
     std::vector<int32_t> h_dist10;   // n*n, from K1 (empty when restraints came from a tbl)
@@ -129,6 +131,8 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
     c3d::DevModel m{};
     const c3d_model& h = c->model;
     m.n = c->n; m.npad = c->npad; m.ntiles = c->ntiles; m.nrep = c->nrep;
+    m.rpw = c->rpw;
+    m.stage_dma = c->stage_dma;
     m.noe_pot = h.noe_pot; m.ang_mode = h.ang_mode;
     m.rs = h.rswitch;
     m.tail_c = h.asym * h.rswitch;
@@ -191,7 +195,7 @@ int upload_targets(c3d_ctx* c, const std::vector<float>& enc) {
 
 void set_dims(c3d_ctx* c, int n) {
     c->n = n;
-    c->npad = (n + 63) / 64 * 64;
+    c->npad = (n + 255) / 256 * 256;   // one column block of the pair kernel = 256 columns
     c->ntiles = (n + c3d::kTileRows - 1) / c3d::kTileRows;
     c->rep_floats = (size_t)3 * c->npad;
 }
@@ -286,13 +290,14 @@ int end_timing(c3d_ctx* c) {
 
 // max over replicas of the RMS force from the FIRE partial sums of the current parity
 int max_rms_force(c3d_ctx* c, double* out) {
-    std::vector<float> h((size_t)c->nrep * c->ntiles * 4);
+    const int nparts = c->ntiles;
+    std::vector<float> h((size_t)c->nrep * nparts * 4);
     HIP_TRY(hipMemcpyAsync(h.data(), c->buf.P[c->parity], sizeof(float) * h.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     double worst = 0;
     for (int r = 0; r < c->nrep; ++r) {
         double ff = 0;
-        for (int t = 0; t < c->ntiles; ++t) ff += h[((size_t)r * c->ntiles + t) * 4 + 1];
+        for (int t = 0; t < nparts; ++t) ff += h[((size_t)r * nparts + t) * 4 + 1];
         worst = std::max(worst, sqrt(ff / (3.0 * c->n)));
     }
     *out = worst;
@@ -417,6 +422,13 @@ extern "C" int c3d_set_schedule(c3d_ctx* c, const c3d_stage* st, int n_stages, c
 extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
     if (!c || !key) return fail(C3D_ERR_INVALID, "c3d_set_option: null argument");
     if (!strcmp(key, "use_graph")) { c->use_graph = value != 0; return C3D_OK; }
+    if (!strcmp(key, "rows_per_wave")) {
+        if (value != 1 && value != 2 && value != 4) return fail(C3D_ERR_INVALID, "rows_per_wave must be 1, 2 or 4");
+        c->rpw = (int)value;
+        drop_graphs(c);
+        return C3D_OK;
+    }
+    if (!strcmp(key, "stage_dma")) { c->stage_dma = value != 0; drop_graphs(c); return C3D_OK; }
     if (!strcmp(key, "graph_chunk")) {
         if (value < 8) return fail(C3D_ERR_INVALID, "graph_chunk must be >= 8");
         c->graph_chunk = (int)value & ~1;   // even: a chunk returns to the starting parity
@@ -510,7 +522,7 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
             HIP_TRY(hipMalloc(&c->buf.X[k], sizeof(float) * nf));
             HIP_TRY(hipMalloc(&c->buf.V[k], sizeof(float) * nf));
             HIP_TRY(hipMalloc(&c->buf.F[k], sizeof(float) * nf));
-            HIP_TRY(hipMalloc(&c->buf.P[k], sizeof(float) * 4 * (size_t)nrep * c->ntiles));
+            HIP_TRY(hipMalloc(&c->buf.P[k], sizeof(float) * 4 * (size_t)nrep * c->ntiles * c3d::kTileRows));
             HIP_TRY(hipMalloc(&c->buf.S[k], sizeof(c3d::FireState) * nrep));
         }
         HIP_TRY(hipMalloc(&c->buf.Vinit, sizeof(float) * nf));
@@ -559,7 +571,7 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMemset(c->buf.V[k], 0, sizeof(float) * nf));
         HIP_TRY(hipMemset(c->buf.F[k], 0, sizeof(float) * nf));
-        HIP_TRY(hipMemset(c->buf.P[k], 0, sizeof(float) * 4 * (size_t)nrep * c->ntiles));
+        HIP_TRY(hipMemset(c->buf.P[k], 0, sizeof(float) * 4 * (size_t)nrep * c->ntiles * c3d::kTileRows));
         HIP_TRY(hipMemset(c->buf.S[k], 0, sizeof(c3d::FireState) * nrep));
     }
     HIP_TRY(hipMemset(c->d_feval, 0, sizeof(float) * nf));
@@ -717,3 +729,11 @@ extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
     for (int r = 0; r < c->nrep; ++r) rank[r] = idx[r];
     return C3D_OK;
 }
+
+#ifdef C3D_STAMPS
+namespace c3d { hipError_t read_stamps(unsigned long long* out); }
+extern "C" int c3d_debug_stamps(unsigned long long* out) {
+    hipError_t e = c3d::read_stamps(out);
+    return e == hipSuccess ? C3D_OK : C3D_ERR_HIP;
+}
+#endif

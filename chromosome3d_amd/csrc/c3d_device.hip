@@ -21,35 +21,56 @@
 
 namespace c3d {
 
+// Diagnostic build only (-DC3D_STAMPS, tools/stamps): phase time stamps of workgroup (tile 0,
+// replica 0), wave 0.  The product build compiles none of this.
+#ifdef C3D_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define C3D_STAMP(k)                                                                   \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define C3D_STAMP(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
+// Wave64 sum on the VALU with DPP (no ds_bpermute / LDS crossbar round trips): 6 v_add_f32_dpp,
+// total in lane 63, broadcast through an SGPR (v_readlane).  gfx9 DPP controls:
+// quad_perm[a,b,c,d] = a|b<<2|c<<4|d<<6, row_mirror 0x140, row_half_mirror 0x141,
+// row_bcast:15 0x142 (row_mask 0xa), row_bcast:31 0x143 (row_mask 0xc).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);          // lanes ^1
+    v += dpp_mov<0x4E>(v);          // lanes ^2
+    v += dpp_mov<0x141>(v);         // row_half_mirror
+    v += dpp_mov<0x140>(v);         // row_mirror
+    v += dpp_mov<0x142, 0xa>(v);    // row_bcast:15
+    v += dpp_mov<0x143, 0xc>(v);    // row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-
-// Transposing butterfly: a[r] is this lane's partial sum for row r (r < 4).  Returns, in every
-// lane l, the sum over all 64 lanes of a[l & 3] — 7 shuffles instead of 4 x 6.
-static_assert(kRowsPerWave == 4, "reduce_rows is written for 4 rows per wave");
-__device__ __forceinline__ float reduce_rows(const float (&a)[kRowsPerWave], int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2;
-    float k01 = b0 ? a[1] : a[0], s01 = b0 ? a[0] : a[1];
-    float k23 = b0 ? a[3] : a[2], s23 = b0 ? a[2] : a[3];
-    k01 += __shfl_xor(s01, 1, 64);
-    k23 += __shfl_xor(s23, 1, 64);
-    float k = b1 ? k23 : k01;
-    const float s = b1 ? k01 : k23;
-    k += __shfl_xor(s, 2, 64);
-#pragma unroll
-    for (int off = 4; off < 64; off <<= 1) k += __shfl_xor(k, off, 64);
-    return k;
+// sum over the low RPW lanes of each quad (RPW in {1,2,4}); valid in lane 0
+template <int RPW>
+__device__ __forceinline__ float quad_sum(float v) {
+    if constexpr (RPW >= 2) v += dpp_mov<0xB1>(v);
+    if constexpr (RPW >= 4) v += dpp_mov<0x4E>(v);
+    return v;
+}
+// uniform per-row values -> the value of row (lane & (RPW-1)) in each lane, plain selects
+template <int RPW>
+__device__ __forceinline__ float row_select(const float (&a)[RPW], int lane) {
+    if constexpr (RPW == 1) return a[0];
+    else if constexpr (RPW == 2) return (lane & 1) ? a[1] : a[0];
+    else return (lane & 2) ? ((lane & 1) ? a[3] : a[2]) : ((lane & 1) ? a[1] : a[0]);
 }
 
 // XCD-aware block -> (tile, replica) map.  Blocks b and b+8 share an XCD (round-robin dispatch,
@@ -80,48 +101,75 @@ __device__ __forceinline__ float noe_grad(float delta, const DevModel& m) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: forces on kRowsPerWave consecutive rows, one wave, lanes across j.
-// On return lane l holds the complete force on row row0 + (l & 3).
+// K2: forces on RPW consecutive rows, one wave, lanes across j.  The target row loads are
+// software-pipelined one j-block ahead (tv = block being computed, tn = block in flight); the
+// caller issues the first block before it stages xyz in LDS (tile_prefetch) so that their
+// L2 latency overlaps the staging.  On return lane l holds the force on row row0 + (l & (RPW-1)).
 // ---------------------------------------------------------------------------------------------
+// One "column block" = 256 columns: lane l owns columns 256*jb + 4l .. 4l+3, so every target
+// load is a 16-byte global_load_dwordx4 and every coordinate read a ds_read_b128 (dword loads
+// are address-rate bound in the texture path: 1 pair per load instruction-lane starves the VALU).
+template <int RPW>
+__device__ __forceinline__ void tile_prefetch(const DevModel& m, const float* __restrict__ tgt, int row0, int lane,
+                                              int jb, float4 (&tv)[RPW]) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+        tv[r] = *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 256 * jb + 4 * lane);
+}
+
 template <int POT, bool GEN>
+__device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, float v, float dx, float dy, float dz,
+                                          float& fx, float& fy, float& fz) {
+    const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
+    const float rinv = __builtin_amdgcn_rsqf(r2);
+    const float d = r2 * rinv;
+    const float t = fabsf(v);
+    const float g = noe_grad<POT, GEN>(d - t, m);
+    float c = (t > 0.0f) ? -p.w_noe * g * rinv : 0.0f;
+    const float q = fmaxf(p.rep_r2 - r2, 0.0f);
+    c += (__float_as_int(v) >= 0) ? p.w_rep4 * q : 0.0f;
+    fx = fmaf(c, dx, fx);
+    fy = fmaf(c, dy, fy);
+    fz = fmaf(c, dz, fz);
+}
+
+template <int POT, bool GEN, int RPW>
 __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p, const float* __restrict__ tgt,
                                             const float* xs, const float* ys, const float* zs, int row0, int lane,
-                                            float& Fx, float& Fy, float& Fz) {
-    float fx[kRowsPerWave], fy[kRowsPerWave], fz[kRowsPerWave];
-    float xi[kRowsPerWave], yi[kRowsPerWave], zi[kRowsPerWave];
-    const float* trow[kRowsPerWave];
+                                            float4 (&tv)[RPW], float& Fx, float& Fy, float& Fz) {
+    float fx[RPW], fy[RPW], fz[RPW];
+    float xi[RPW], yi[RPW], zi[RPW];
 #pragma unroll
-    for (int r = 0; r < kRowsPerWave; ++r) {
+    for (int r = 0; r < RPW; ++r) {
         const int row = min(row0 + r, m.n - 1);
         xi[r] = xs[row]; yi[r] = ys[row]; zi[r] = zs[row];
-        trow[r] = tgt + (size_t)row * m.npad;
         fx[r] = fy[r] = fz[r] = 0.0f;
     }
-    for (int j = lane; j < m.npad; j += 64) {
-        const float xj = xs[j], yj = ys[j], zj = zs[j];
+    const int nblk = m.npad >> 8;
+    for (int jb = 0; jb < nblk; ++jb) {
+        float4 tn[RPW];
+        const int jn = jb + 1 < nblk ? jb + 1 : jb;     // last block re-reads itself (in bounds)
+        tile_prefetch<RPW>(m, tgt, row0, lane, jn, tn);  // next block in flight while this one computes
+        const int j = 256 * jb + 4 * lane;
+        const float4 xj = *reinterpret_cast<const float4*>(xs + j);
+        const float4 yj = *reinterpret_cast<const float4*>(ys + j);
+        const float4 zj = *reinterpret_cast<const float4*>(zs + j);
 #pragma unroll
-        for (int r = 0; r < kRowsPerWave; ++r) {
-            const float v = trow[r][j];
-            const float dx = xi[r] - xj, dy = yi[r] - yj, dz = zi[r] - zj;
-            const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
-            const float rinv = __builtin_amdgcn_rsqf(r2);
-            const float d = r2 * rinv;
-            const float t = fabsf(v);
-            const float g = noe_grad<POT, GEN>(d - t, m);
-            float c = (t > 0.0f) ? -p.w_noe * g * rinv : 0.0f;
-            const float q = fmaxf(p.rep_r2 - r2, 0.0f);
-            c += (__float_as_int(v) >= 0) ? p.w_rep4 * q : 0.0f;
-            fx[r] = fmaf(c, dx, fx[r]);
-            fy[r] = fmaf(c, dy, fy[r]);
-            fz[r] = fmaf(c, dz, fz[r]);
+        for (int r = 0; r < RPW; ++r) {
+            pair_term<POT, GEN>(m, p, tv[r].x, xi[r] - xj.x, yi[r] - yj.x, zi[r] - zj.x, fx[r], fy[r], fz[r]);
+            pair_term<POT, GEN>(m, p, tv[r].y, xi[r] - xj.y, yi[r] - yj.y, zi[r] - zj.y, fx[r], fy[r], fz[r]);
+            pair_term<POT, GEN>(m, p, tv[r].z, xi[r] - xj.z, yi[r] - yj.z, zi[r] - zj.z, fx[r], fy[r], fz[r]);
+            pair_term<POT, GEN>(m, p, tv[r].w, xi[r] - xj.w, yi[r] - yj.w, zi[r] - zj.w, fx[r], fy[r], fz[r]);
         }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) tv[r] = tn[r];
     }
     // chain terms: pseudo-bond (i,i+-1) and pseudo-angle (i,i+-2), lanes 0..3 take one neighbour each
     {
         const int off = lane < 2 ? lane - 2 : lane - 1;   // -2,-1,+1,+2 for lanes 0..3
         const int sep = off < 0 ? -off : off;
 #pragma unroll
-        for (int r = 0; r < kRowsPerWave; ++r) {
+        for (int r = 0; r < RPW; ++r) {
             const int row = min(row0 + r, m.n - 1);
             const int jn = row + off;
             if (lane < 4 && jn >= 0 && jn < m.n) {
@@ -139,97 +187,144 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
             }
         }
     }
-    Fx = reduce_rows(fx, lane);
-    Fy = reduce_rows(fy, lane);
-    Fz = reduce_rows(fz, lane);
+    float sx[RPW], sy[RPW], sz[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) { sx[r] = wave_sum(fx[r]); sy[r] = wave_sum(fy[r]); sz[r] = wave_sum(fz[r]); }
+    Fx = row_select<RPW>(sx, lane);
+    Fy = row_select<RPW>(sy, lane);
+    Fz = row_select<RPW>(sz, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3/K4: one SA step (MD leap-frog or FIRE) for all replicas
-// LDS: xs[npad] ys[npad] zs[npad] | vown[3][kTileRows] | scal[16] | wpart[kWaves][4]
+// K3/K4: one SA step (MD leap-frog or FIRE) for all replicas.
+// Workgroup = kTileRows / RPW waves; LDS: xs[npad] ys[npad] zs[npad] | vown[3][kTileRows].
+// Latency plan of one workgroup (the kernel is latency-, not bandwidth-bound at N ~ 500):
+//   1. issue every independent global load up front: first target block of the wave's rows, the
+//      previous step's partial sums, own-row velocities, the bead coordinates
+//   2. each WAVE reduces the partial sums itself (no barrier), coordinates go to LDS, ONE barrier
+//   3. pair loop with the target loads pipelined one block ahead
+//   4. lanes 0..RPW-1 finish one row each and store this wave's partial sums (no second barrier)
 // ---------------------------------------------------------------------------------------------
-template <int POT, bool GEN>
-__global__ __launch_bounds__(kBlock) void k_step(const DevModel m, const DevStep p, const DevFire fp,
-                                                const float* __restrict__ tgt, const float* __restrict__ xin,
-                                                float* __restrict__ xout, const float* __restrict__ vin,
-                                                float* __restrict__ vout, const float* __restrict__ fin,
-                                                float* __restrict__ fout, const float* __restrict__ vinit,
-                                                const float* __restrict__ pin, float* __restrict__ pout,
-                                                const FireState* __restrict__ sin, FireState* __restrict__ sout) {
+__device__ __forceinline__ float4 wave_sum4(float4 a) {
+    return make_float4(wave_sum(a.x), wave_sum(a.y), wave_sum(a.z), wave_sum(a.w));
+}
+
+// async global -> LDS copy of `count` floats (count % 256 == 0), 16 bytes per lane per instruction
+// (global_load_lds_dwordx4: LDS address = wave-uniform base + lane*16, no VGPR round trip).  The
+// caller's __syncthreads() waits for it (hipcc emits s_waitcnt vmcnt(0) before the barrier).
+template <int BLOCK>
+__device__ __forceinline__ void lds_dma_copy(const float* __restrict__ src, float* dst, int count, int tid) {
+    const int lane = tid & 63;
+    for (int b = 4 * tid; b < count; b += 4 * BLOCK)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + b),
+                                         (void __attribute__((address_space(3)))*)(dst + (b - 4 * lane)), 16, 0, 0);
+}
+
+template <int POT, bool GEN, int RPW>
+__global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
+    const float* __restrict__ pin, const float* __restrict__ xin, const float* __restrict__ tgt,
+    const float* __restrict__ vin, const float* __restrict__ fin, const float* __restrict__ vinit,
+    const FireState* __restrict__ sin, float* __restrict__ xout, float* __restrict__ vout, float* __restrict__ fout,
+    float* __restrict__ pout, FireState* __restrict__ sout, const DevModel m, const DevStep p, const DevFire fp) {
+    constexpr int WAVES = kTileRows / RPW;
+    constexpr int BLOCK = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int tile, rep;
     if (!block_to_tile(m, tile, rep)) return;
+    C3D_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npad = m.npad;
     float* xs = smem;
     float* ys = smem + npad;
     float* zs = smem + 2 * npad;
     float* vown = smem + 3 * npad;              // [3][kTileRows]
-    float* scal = vown + 3 * kTileRows;         // [16]
-    float* wpart = scal + 16;                   // [kWaves][4]
+    float* wpart = vown + 3 * kTileRows;        // [WAVES][4]
     const size_t roff = (size_t)rep * 3 * npad;
     const int tile_row0 = tile * kTileRows;
+    const int row0 = tile_row0 + wave * RPW;
+    const int row = row0 + (lane & (RPW - 1));  // the row this lane finishes (lanes < RPW only)
+    const bool finisher = lane < RPW && row < m.n;
+    const size_t ix = roff + row, iy = ix + npad, iz = iy + npad;
     const bool is_md = p.kind == 0 || p.kind == 1 || p.kind == 4;
+    const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
 
-    // ---- prologue: global scalars from the previous step's per-tile partial sums --------------
-    if (wave == 0 && (p.kind == 0 || p.kind == 1 || p.kind == 2)) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    // ---- 1. every independent global load is issued before anything waits -------------------
+    // coordinates: MD / begin kinds copy them straight into LDS (async DMA); FIRE updates them
+    // in registers first (below) and loads its first bead here
+    float bx = 0, by = 0, bz = 0, bvx = 0, bvy = 0, bvz = 0, bfx = 0, bfy = 0, bfz = 0;
+    if (p.kind != 2) {
+        if (m.stage_dma) lds_dma_copy<BLOCK>(xin + roff, smem, 3 * npad, tid);
+        else for (int b = 4 * tid; b < 3 * npad; b += 4 * BLOCK) *reinterpret_cast<float4*>(smem + b) = *reinterpret_cast<const float4*>(xin + roff + b);
+    } else if (tid < npad) {
+        bx = xin[roff + tid]; by = xin[roff + npad + tid]; bz = xin[roff + 2 * npad + tid];
+        bvx = vin[roff + tid]; bvy = vin[roff + npad + tid]; bvz = vin[roff + 2 * npad + tid];
+        bfx = fin[roff + tid]; bfy = fin[roff + npad + tid]; bfz = fin[roff + 2 * npad + tid];
+    }
+    float4 psum = make_float4(0, 0, 0, 0);
+    if (needs_partials) {   // one float4 per tile; ntiles <= 64 for N <= 1024
         const float4* pp = reinterpret_cast<const float4*>(pin) + (size_t)rep * m.ntiles;
         for (int t = lane; t < m.ntiles; t += 64) {
             const float4 q = pp[t];
-            s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
-        }
-        s0 = wave_sum_d(s0); s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); s3 = wave_sum_d(s3);
-        if (lane == 0) {
-            if (is_md) {  // s0 = sum v^2, s1..s3 = sum v
-                const float tprev = fmaxf(m.t_fac * (float)s0, 1e-2f);
-                float lam;
-                if (p.kind == 0) lam = sqrtf(fmaxf(1.0f + p.dt * m.fbeta * (p.t_bath / tprev - 1.0f), 0.0f));
-                else lam = sqrtf(p.t_bath / tprev);
-                scal[0] = lam;
-                scal[1] = (float)s1 * m.inv_n; scal[2] = (float)s2 * m.inv_n; scal[3] = (float)s3 * m.inv_n;
-            } else {      // FIRE: s0 = v.F, s1 = F.F, s2 = v.v
-                FireState st = sin[rep];
-                float keep, mix;
-                if (s0 > 0.0) {
-                    keep = 1.0f - st.alpha;
-                    mix = st.alpha * sqrtf((float)s2 / fmaxf((float)s1, 1e-30f));
-                    if (st.npos > fp.n_min) {
-                        st.dt = fminf(st.dt * fp.f_inc, fp.dt_max);
-                        st.alpha *= fp.f_alpha;
-                    }
-                    st.npos += 1;
-                } else {
-                    keep = 0.0f; mix = 0.0f;
-                    st.alpha = fp.alpha_start;
-                    st.dt *= fp.f_dec;
-                    st.npos = 0;
-                }
-                scal[0] = keep; scal[1] = mix; scal[2] = st.dt;
-                if (tile == 0) sout[rep] = st;
-            }
+            psum.x += q.x; psum.y += q.y; psum.z += q.z; psum.w += q.w;
         }
     }
-    if (p.kind == 3 && tid == 0 && tile == 0) {
-        FireState st; st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0;
-        sout[rep] = st;
+    float4 tv[RPW];
+    if (p.kind != 4) tile_prefetch<RPW>(m, tgt, row0, lane, 0, tv);
+    float vx0 = 0.0f, vy0 = 0.0f, vz0 = 0.0f;
+    if (finisher && is_md) {
+        const float* vsrc = p.kind == 4 ? vinit : vin;
+        vx0 = vsrc[ix]; vy0 = vsrc[iy]; vz0 = vsrc[iz];
     }
-    __syncthreads();
+    FireState st;
+    st.dt = 0.0f; st.alpha = 0.0f; st.npos = 0; st.pad = 0;
+    if (p.kind == 2) st = sin[rep];
+    C3D_STAMP(1);
 
-    // ---- stage bead coordinates of this replica in LDS ---------------------------------------
+    // ---- 2. scalars per wave (no barrier), FIRE bead update, coordinates in LDS ---------------
+    float lam = 1.0f, cmx = 0.0f, cmy = 0.0f, cmz = 0.0f;   // MD
+    if (needs_partials) {
+        psum = wave_sum4(psum);
+        if (is_md) {          // psum = (sum v^2, sum vx, sum vy, sum vz) of the previous half step
+            const float tprev = fmaxf(m.t_fac * psum.x, 1e-2f);
+            if (p.kind == 0) lam = sqrtf(fmaxf(1.0f + p.dt * m.fbeta * (p.t_bath / tprev - 1.0f), 0.0f));
+            else lam = sqrtf(p.t_bath / tprev);
+            cmx = psum.y * m.inv_n; cmy = psum.z * m.inv_n; cmz = psum.w * m.inv_n;
+        }
+    }
     if (p.kind == 2) {
-        // FIRE update of ALL beads (redundantly per workgroup: O(N) next to the O(16 N) pair work),
-        // own rows are also written back.  x' = x + clamp(dt * v'), v' = keep*v + mix*F + acc*dt*F
-        const float keep = scal[0], mix = scal[1], dt = scal[2];
-        const float a = dt * m.acc;
-        for (int b = tid; b < npad; b += kBlock) {
-            float x = xin[roff + b], y = xin[roff + npad + b], z = xin[roff + 2 * npad + b];
+        // FIRE (Bitzek et al. 2006): psum = (v.F, F.F, v.v).  Every wave derives the same new state.
+        float keep, mix;
+        if (psum.x > 0.0f) {
+            keep = 1.0f - st.alpha;
+            mix = st.alpha * sqrtf(psum.z / fmaxf(psum.y, 1e-30f));
+            if (st.npos > fp.n_min) {
+                st.dt = fminf(st.dt * fp.f_inc, fp.dt_max);
+                st.alpha *= fp.f_alpha;
+            }
+            st.npos += 1;
+        } else {
+            keep = 0.0f; mix = 0.0f;
+            st.alpha = fp.alpha_start;
+            st.dt *= fp.f_dec;
+            st.npos = 0;
+        }
+        if (tile == 0 && tid == 0) sout[rep] = st;
+        // update ALL beads (redundantly per workgroup: O(N) next to the O(16 N) pair work); own rows
+        // are written back.  v' = keep*v + mix*F + a*F ; x' = x + clamp(dt*v')
+        const float dt = st.dt, a = st.dt * m.acc;
+        for (int b = tid; b < npad; b += BLOCK) {
+            float x = bx, y = by, z = bz, vx = bvx, vy = bvy, vz = bvz;
+            const float fx = bfx, fy = bfy, fz = bfz;
+            const int bn = b + BLOCK;
+            if (bn < npad) {   // next bead of this thread in flight while this one is updated
+                bx = xin[roff + bn]; by = xin[roff + npad + bn]; bz = xin[roff + 2 * npad + bn];
+                bvx = vin[roff + bn]; bvy = vin[roff + npad + bn]; bvz = vin[roff + 2 * npad + bn];
+                bfx = fin[roff + bn]; bfy = fin[roff + npad + bn]; bfz = fin[roff + 2 * npad + bn];
+            }
             if (b < m.n) {
-                const float fx = fin[roff + b], fy = fin[roff + npad + b], fz = fin[roff + 2 * npad + b];
-                float vx = vin[roff + b], vy = vin[roff + npad + b], vz = vin[roff + 2 * npad + b];
                 vx = keep * vx + mix * fx; vy = keep * vy + mix * fy; vz = keep * vz + mix * fz;
                 vx = fmaf(a, fx, vx); vy = fmaf(a, fy, vy); vz = fmaf(a, fz, vz);
-                float dxs = dt * vx, dys = dt * vy, dzs = dt * vz;
+                const float dxs = dt * vx, dys = dt * vy, dzs = dt * vz;
                 const float d2 = dxs * dxs + dys * dys + dzs * dzs;
                 const float sc = d2 > fp.max_step * fp.max_step ? fp.max_step * __builtin_amdgcn_rsqf(d2) : 1.0f;
                 x = fmaf(sc, dxs, x); y = fmaf(sc, dys, y); z = fmaf(sc, dzs, z);
@@ -242,38 +337,38 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevModel m, const DevStep
             }
             xs[b] = x; ys[b] = y; zs[b] = z;
         }
-    } else {
-        for (int b = tid; b < 3 * npad; b += kBlock) smem[b] = xin[roff + b];
+    } else if (p.kind == 3 && tile == 0 && tid == 0) {
+        FireState s0; s0.dt = fp.dt_start; s0.alpha = fp.alpha_start; s0.npos = 0; s0.pad = 0;
+        sout[rep] = s0;
     }
+    C3D_STAMP(2);
     __syncthreads();
+    C3D_STAMP(3);
 
-    // ---- K2: pair forces for this wave's rows ------------------------------------------------
+    // ---- 3. K2: pair forces for this wave's rows ---------------------------------------------
     float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
-    const int row0 = tile_row0 + wave * kRowsPerWave;
-    if (p.kind != 4) tile_forces<POT, GEN>(m, p, tgt, xs, ys, zs, row0, lane, Fx, Fy, Fz);
+    if (p.kind != 4) tile_forces<POT, GEN, RPW>(m, p, tgt, xs, ys, zs, row0, lane, tv, Fx, Fy, Fz);
 
-    // ---- epilogue: lanes 0..kRowsPerWave-1 finish one row each --------------------------------
-    float q0 = 0, q1 = 0, q2 = 0, q3 = 0;   // this lane's contribution to the tile partial sums
-    const int row = row0 + lane;
-    if (lane < kRowsPerWave && row < m.n) {
-        const size_t ix = roff + row, iy = roff + npad + row, iz = roff + 2 * npad + row;
+    C3D_STAMP(4);
+    // ---- 4. epilogue: lanes 0..RPW-1 finish one row each --------------------------------------
+    float4 q = make_float4(0, 0, 0, 0);   // this lane's contribution to the tile's partial sums
+    if (finisher) {
         if (is_md) {
             float vx, vy, vz;
-            if (p.kind == 4) {            // MD begin: load the Maxwell velocities, no move
-                vx = vinit[ix]; vy = vinit[iy]; vz = vinit[iz];
+            if (p.kind == 4) {            // MD begin: take the Maxwell velocities, no move
+                vx = vx0; vy = vy0; vz = vz0;
                 xout[ix] = xs[row]; xout[iy] = ys[row]; xout[iz] = zs[row];
             } else {
-                const float lam = scal[0];
                 const float a = p.dt * m.acc;
-                vx = fmaf(a, Fx, lam * (vin[ix] - scal[1]));
-                vy = fmaf(a, Fy, lam * (vin[iy] - scal[2]));
-                vz = fmaf(a, Fz, lam * (vin[iz] - scal[3]));
+                vx = fmaf(a, Fx, lam * (vx0 - cmx));
+                vy = fmaf(a, Fy, lam * (vy0 - cmy));
+                vz = fmaf(a, Fz, lam * (vz0 - cmz));
                 xout[ix] = fmaf(p.dt, vx, xs[row]);
                 xout[iy] = fmaf(p.dt, vy, ys[row]);
                 xout[iz] = fmaf(p.dt, vz, zs[row]);
             }
             vout[ix] = vx; vout[iy] = vy; vout[iz] = vz;
-            q0 = vx * vx + vy * vy + vz * vz; q1 = vx; q2 = vy; q3 = vz;
+            q = make_float4(vx * vx + vy * vy + vz * vz, vx, vy, vz);
         } else {
             float vx = 0.0f, vy = 0.0f, vz = 0.0f;
             if (p.kind == 2) {
@@ -284,39 +379,48 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevModel m, const DevStep
                 vout[ix] = 0.0f; vout[iy] = 0.0f; vout[iz] = 0.0f;
             }
             fout[ix] = Fx; fout[iy] = Fy; fout[iz] = Fz;
-            q0 = vx * Fx + vy * Fy + vz * Fz;
-            q1 = Fx * Fx + Fy * Fy + Fz * Fz;
-            q2 = vx * vx + vy * vy + vz * vz;
+            q = make_float4(vx * Fx + vy * Fy + vz * Fz, Fx * Fx + Fy * Fy + Fz * Fz, vx * vx + vy * vy + vz * vz, 0.0f);
         }
     }
-    // partial sums: lanes 0..3 of each wave -> wave total -> fixed-order sum over the 4 waves
-#pragma unroll
-    for (int off = 1; off < kRowsPerWave; off <<= 1) {
-        q0 += __shfl_xor(q0, off, 64); q1 += __shfl_xor(q1, off, 64);
-        q2 += __shfl_xor(q2, off, 64); q3 += __shfl_xor(q3, off, 64);
-    }
-    if (lane == 0) { wpart[wave * 4 + 0] = q0; wpart[wave * 4 + 1] = q1; wpart[wave * 4 + 2] = q2; wpart[wave * 4 + 3] = q3; }
+    q.x = quad_sum<RPW>(q.x); q.y = quad_sum<RPW>(q.y); q.z = quad_sum<RPW>(q.z); q.w = quad_sum<RPW>(q.w);
+    // tile partial sums: fixed-order sum over the waves (deterministic)
+    if (lane == 0) reinterpret_cast<float4*>(wpart)[wave] = q;
     __syncthreads();
     if (tid == 0) {
         float4 t = make_float4(0, 0, 0, 0);
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) { t.x += wpart[w * 4]; t.y += wpart[w * 4 + 1]; t.z += wpart[w * 4 + 2]; t.w += wpart[w * 4 + 3]; }
+        for (int w = 0; w < WAVES; ++w) {
+            const float4 u = reinterpret_cast<float4*>(wpart)[w];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
         reinterpret_cast<float4*>(pout)[(size_t)rep * m.ntiles + tile] = t;
     }
+    C3D_STAMP(5);
 }
 
-static size_t step_lds_bytes(const DevModel& m) {
-    return sizeof(float) * ((size_t)3 * m.npad + 3 * kTileRows + 16 + kWaves * 4);
-}
+#ifdef C3D_STAMPS
+hipError_t read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16); }
+#endif
 
+static size_t step_lds_bytes(const DevModel& m) { return sizeof(float) * ((size_t)3 * m.npad + 3 * kTileRows + 4 * kTileRows); }
+
+template <int POT, bool GEN, int RPW>
+static hipError_t launch_step_r(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
+                                hipStream_t s) {
+    const int q = par ^ 1;
+    hipLaunchKernelGGL((k_step<POT, GEN, RPW>), dim3(grid_blocks(m)), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
+                       b.P[par], b.X[par], b.tgt, b.V[par], b.F[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.F[q], b.P[q],
+                       b.S[q], m, p, fp);
+    return hipGetLastError();
+}
 template <int POT, bool GEN>
 static hipError_t launch_step_t(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
                                 hipStream_t s) {
-    const int q = par ^ 1;
-    hipLaunchKernelGGL((k_step<POT, GEN>), dim3(grid_blocks(m)), dim3(kBlock), step_lds_bytes(m), s, m, p, fp, b.tgt,
-                       b.X[par], b.X[q], b.V[par], b.V[q], b.F[par], b.F[q], b.Vinit, b.P[par], b.P[q], b.S[par],
-                       b.S[q]);
-    return hipGetLastError();
+    switch (m.rpw) {
+        case 1: return launch_step_r<POT, GEN, 1>(m, p, fp, b, par, s);
+        case 2: return launch_step_r<POT, GEN, 2>(m, p, fp, b, par, s);
+        default: return launch_step_r<POT, GEN, 4>(m, p, fp, b, par, s);
+    }
 }
 
 hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int parity,
@@ -348,11 +452,13 @@ __global__ __launch_bounds__(kBlock) void k_eval_forces(const DevModel m, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npad = m.npad;
     const size_t roff = (size_t)rep * 3 * npad;
+    const int row0 = tile * kTileRows + wave * kRowsPerWave;
+    float4 tv[kRowsPerWave];
+    tile_prefetch<kRowsPerWave>(m, tgt, row0, lane, 0, tv);
     for (int b = tid; b < 3 * npad; b += kBlock) smem[b] = xin[roff + b];
     __syncthreads();
     float Fx, Fy, Fz;
-    const int row0 = tile * kTileRows + wave * kRowsPerWave;
-    tile_forces<POT, GEN>(m, p, tgt, smem, smem + npad, smem + 2 * npad, row0, lane, Fx, Fy, Fz);
+    tile_forces<POT, GEN, kRowsPerWave>(m, p, tgt, smem, smem + npad, smem + 2 * npad, row0, lane, tv, Fx, Fy, Fz);
     const int row = row0 + lane;
     if (lane < kRowsPerWave && row < m.n) {
         fout[roff + row] = Fx;

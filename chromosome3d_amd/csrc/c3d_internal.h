@@ -20,6 +20,8 @@ constexpr float kPadCoord = 1.0e4f;
 
 struct DevModel {
     int n, npad, ntiles, nrep;
+    int stage_dma;                 // 1: coordinates staged with global_load_lds (async), 0: through registers
+    int rpw;                       // rows per wave of the step kernel (1, 2 or 4); waves/WG = 16/rpw
     int noe_pot, ang_mode;
     float rs, tail_c, tail_b;      // soft tail: dE/dD = tail_c - tail_b / D^2  (D > rs)
     float k_bond2, b0;             // 2*k_bond
@@ -50,7 +52,7 @@ struct FireState {   // per replica, double buffered
     int npos, pad;
 };
 
-// All device pointers of one context.  Layouts (npad = n rounded up to 64):
+// All device pointers of one context.  Layouts (npad = n rounded up to 256, one column block):
 //   tgt   [n][npad]            encoded restraint target (see encode_target)
 //   X,V,F [2][nrep][3][npad]   SoA coordinates / velocities / forces, double buffered by step parity
 //   Vinit [nrep][3][npad]

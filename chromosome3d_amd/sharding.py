@@ -45,6 +45,9 @@ def gather_records(rec, device=None):
     """all_gather of per-rank record blocks (possibly different M per rank).  Returns the
     concatenation ordered by replica id on every rank.  Without an initialised process group
     this is the identity."""
+    import sys
+    if "torch" not in sys.modules:          # single process: nothing to gather, do not pull torch in
+        return rec[np.argsort(rec[:, 0], kind="stable")]
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
