@@ -1,0 +1,134 @@
+#!/usr/bin/perl -w
+# chromosome3D_amd.pl — driver with the command line of the reference's chromosome3D.pl
+# (-i|-if <IF matrix> -o <outdir> [-k 11] [-a 0.5] [-m 20] [-h]; reference :28-46, usage :2530-2557)
+# whose solver leg is the MI355X library instead of CNS:
+#
+#   reference                                        here
+#   IF2dist_new/dist2rr/carr2tbl (Perl, :87-89)      K1 kernel + host writers inside c3d_solve
+#   build_extended (2 CNS runs, :102)                not needed (bead model, no pseudo-protein)
+#   build_models: job.sh -> cns_solve < dgsa.inp     job.sh -> c3d_solve (C ABI of libc3d.so)
+#   assess_dgsa (:106, :769-829)                     same ranking / table / renaming, below
+#
+# The FFI is the C ABI in include/c3d.h; this script reaches it through the c3d_solve
+# executable (always available); INTEGRATION.md shows the XS binding for in-process calls.
+use strict;
+use warnings;
+use Cwd 'abs_path';
+use File::Basename;
+use File::Copy;
+use Getopt::Long;
+
+my ($help, $dir_out, $file_if);
+my ($K, $ALPHA, $MODELS) = (11, 0.5, 20);        # chromosome3D.pl:18-21
+my ($SEED, $DEVICE, $DISTRELAX) = (82364, 0, 0.5);  # :980, :74
+GetOptions("h" => \$help, "o=s" => \$dir_out, "k=i" => \$K, "a=s" => \$ALPHA, "m=i" => \$MODELS,
+           "i|if=s" => \$file_if, "seed=i" => \$SEED, "device=i" => \$DEVICE)
+	or die "ERROR! Error in command line arguments!\n";
+usage() if $help;
+usage("Input IF matrix not found!") if not defined $file_if;
+usage("Output directory not defined!") if not defined $dir_out;
+usage("Input IF file $file_if does not exist!") if not -f $file_if;
+
+my $solver = $ENV{C3D_SOLVE} || abs_path(dirname(abs_path($0))."/../chromosome3d_amd/_lib/c3d_solve");
+die "ERROR! c3d_solve not found at $solver (build: python -c 'import __graft_entry__ as g; g.build()')\n" if not -x $solver;
+
+mkdir $dir_out or die "ERROR! Could not create output directory $dir_out!\n" if not -d $dir_out;
+print "Start Time : ".(localtime)." [$0]\n";
+print "Input      : $file_if\nOutput Dir : $dir_out\nScaling(K) : $K\nAlpha      : $ALPHA\n";
+print "Effective Conversion Equation is : D = $K * mean(IF^$ALPHA) / IF^$ALPHA\n";
+
+my $ID = basename($file_if, ".txt");
+# the reference wipes the whole output directory (`rm -f $dir_out/*`, :56); we only remove what a
+# previous run of this driver left there
+unlink glob("$dir_out/${ID}_*.pdb"), glob("$dir_out/iam.*");
+unlink map { "$dir_out/$_" } ("$ID.dist", "$ID.rr", "contact.tbl", "job.sh", "job.log", "model_info.log", "contact_violation.txt");
+copy($file_if, "$dir_out/$ID.txt") or die "ERROR! cannot copy $file_if: $!\n" if abs_path($file_if) ne (abs_path("$dir_out/$ID.txt") || "");
+chdir $dir_out or die $!;
+
+# (B) build models — the process boundary of the reference, same sentinel protocol (:258-288)
+open my $job, ">", "job.sh" or die $!;
+print $job "#!/bin/bash\necho \"starting c3d_solve..\"\ntouch iam.running\n";
+print $job "\"$solver\" --if \"$ID.txt\" --out . --id \"$ID\" -k $K -a $ALPHA -m $MODELS --seed $SEED --device $DEVICE\n";
+print $job "if [ -f \"${ID}_${MODELS}.pdb\" ]; then\n   rm -f iam.running\n   echo \"trial structures written.\"\n   exit\nfi\n";
+print $job "echo \"ERROR! Final structures not found!\"\nmv iam.running iam.failed 2>/dev/null || touch iam.failed\n";
+close $job;
+chmod 0755, "job.sh";
+print "(B) Build models using libc3d (MI355X)..\nStarting job [$dir_out/job.sh > job.log]\n";
+system("./job.sh > job.log 2>&1");
+die "ERROR! Something went wrong while running c3d_solve! Check job.log!\n".`tail -n 5 job.log` if -f "iam.failed" or not -f "${ID}_${MODELS}.pdb";
+my ($restraints) = `cat job.log` =~ /Restraints : (\d+)/;
+print "L          : ".first_line_fields("$ID.txt")."\n";
+print "Restraints : ".($restraints // "?")." lines in tbl file\n";
+
+# (C) assess models: rank by int(REMARK noe) ascending (:796-802), table (:804-810), top 5 (:822-828)
+print "(C) Assess models..\n";
+my @tbl = read_tbl("contact.tbl");
+my %e_noe;
+foreach my $pdb (glob("./${ID}_*.pdb")) {
+	next if $pdb =~ /_model\d+\.pdb$/;
+	open my $fh, "<", $pdb or die $!;
+	my $v;
+	while (<$fh>) { if (/^REMARK noe/) { (my $t = $_) =~ s/\s+//g; $v = (split /=/, $t)[1]; } }
+	close $fh;
+	die "ERROR! $pdb has no REMARK noe line!\n" if not defined $v;
+	$e_noe{$pdb} = int($v);
+}
+open my $log, ">>", "model_info.log" or die $!;
+print "\nNOE_SATISFIED(+-${DISTRELAX}A)  SUM_OF_DEVIATIONS>= 0.2  PDB\n";
+foreach my $pdb (sort { $e_noe{$b} <=> $e_noe{$a} || $a cmp $b } keys %e_noe) {
+	my %xyz = read_ca($pdb);
+	my ($count, $total, $sum_dev) = (0, 0, 0.0);
+	foreach my $r (@tbl) {
+		my ($i, $j, $t) = @$r;
+		my $d = sprintf "%.3f", sqrt(($xyz{$i}[0]-$xyz{$j}[0])**2 + ($xyz{$i}[1]-$xyz{$j}[1])**2 + ($xyz{$i}[2]-$xyz{$j}[2])**2);
+		$count++ if $d < $t + $DISTRELAX;
+		$count-- if $d < $t - $DISTRELAX;
+		$sum_dev += $d - $t if $d > $t + 0.2;
+		$sum_dev += $t - $d if $d < $t - 0.2;
+		$total++;
+	}
+	printf "%-9s             %-9s                %-25s\n", "$count/$total", (sprintf "%.2f", $sum_dev), basename($pdb, ".pdb");
+	print $log "$pdb\n".join("", grep { /^REMARK/ } do { open my $f, "<", $pdb or die $!; <$f> })."\n";
+}
+close $log;
+print "\n";
+my $rank = 1;
+foreach my $pdb (sort { $e_noe{$a} <=> $e_noe{$b} || $a cmp $b } keys %e_noe) {
+	print "model$rank.pdb <= $pdb\n";
+	rename $pdb, "${ID}_model$rank.pdb" or die $!;
+	last if ++$rank > 5;
+}
+print "\nFinished [$0]: ".(localtime)."\n";
+
+sub first_line_fields { open my $f, "<", shift or die $!; my $l = <$f>; close $f; $l =~ s/^\s+//; my @t = split /\s+/, $l; return scalar @t; }
+sub read_tbl {
+	my @rows;
+	open my $f, "<", shift or die $!;
+	while (<$f>) { tr/()/  /; my @c = split; next if not @c; die "bad tbl row: $_" if $c[0] !~ /^assign/; push @rows, [$c[2], $c[7], $c[11]]; }
+	close $f;
+	return @rows;
+}
+sub read_ca {
+	my %xyz;
+	open my $f, "<", shift or die $!;
+	while (<$f>) { next if !/^ATOM/; (my $an = substr($_, 12, 4)) =~ s/\s+//g; next if $an ne "CA";
+		(my $rn = substr($_, 22, 5)) =~ s/\s+//g; $xyz{$rn} = [substr($_, 30, 8) + 0, substr($_, 38, 8) + 0, substr($_, 46, 8) + 0]; }
+	close $f;
+	return %xyz;
+}
+sub usage {
+	my $msg = shift;
+	print "\nERROR! $msg\n" if defined $msg;
+	print <<"EOU";
+
+PARAM        DESCRIPTION
+-i | -if  :  Input IF matrix (N x N, whitespace separated)
+-o        :  Output directory
+-k        :  Scaling constant K (default 11)
+-a        :  Alpha for the IF -> distance conversion (default 0.5)
+-m        :  Number of models to generate (default 20)
+--seed    :  RNG seed (default 82364)   --device : GPU index (default 0)
+Example: $0 -i ./input/chr22_1mb_matrix.txt -o ./output/chr22_1mb
+EOU
+	exit(defined $msg ? 1 : 0);
+}

@@ -10,7 +10,7 @@ constexpr float kBoltz = 0.0019872f;  // kcal/mol/K (X-PLOR/CNS AKMA)
 constexpr float kAccel = 418.4f;      // kcal/mol/A/amu -> A/ps^2
 
 // rows of the pair matrix owned by one workgroup = kWaves * kRowsPerWave
-constexpr int kWaves = 4;
+constexpr int kWaves = 2;
 constexpr int kRowsPerWave = 4;
 constexpr int kTileRows = kWaves * kRowsPerWave;
 constexpr int kBlock = kWaves * 64;

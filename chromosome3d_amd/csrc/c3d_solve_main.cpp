@@ -8,6 +8,8 @@
 //
 // Success convention of the reference: <ID>_<M>.pdb exists, iam.running removed; on failure
 // iam.running is renamed iam.failed and the exit code is non-zero (:266-283).
+#include <sys/stat.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,6 +79,7 @@ int main(int argc, char** argv) {
         if (base.size() > 4 && base.substr(base.size() - 4) == ".txt") base.resize(base.size() - 4);
         id = base;
     }
+    mkdir(out_dir.c_str(), 0755);   // like the reference (:45): create the output directory if missing
     { FILE* f = fopen((out_dir + "/iam.running").c_str(), "w"); if (!f) { fprintf(stderr, "c3d_solve: cannot write into %s\n", out_dir.c_str()); return 1; } fclose(f); }
     remove((out_dir + "/iam.failed").c_str());
 

@@ -1,0 +1,102 @@
+"""The drop-in boundary as a user meets it: c3d_solve (stand-in for `cns_solve < dgsa.inp`),
+c3d_score (spearman_IF_pdb.pl) and the Perl driver with the reference's command line."""
+import hashlib
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.util import GOLD, golden, load_if, model_pdb, REF_SPEARMAN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "chromosome3d_amd", "_lib")
+MATRIX = os.path.join(GOLD, "inputs", "chr21_1mb_matrix.txt")
+G = golden()
+
+
+def test_c3d_score_matches_reference_table(built):
+    out = subprocess.run([os.path.join(LIBDIR, "c3d_score"), MATRIX, model_pdb("chr21_1mb")], capture_output=True, text=True)
+    assert out.returncode == 0
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "SRCC\tPDB" and lines[1].split("\t")[0] == "%.3f" % REF_SPEARMAN["chr21_1mb"]
+    bad = subprocess.run([os.path.join(LIBDIR, "c3d_score"), MATRIX, model_pdb("chr13_1mb")], capture_output=True, text=True)
+    assert bad.returncode != 0 and "mismatch in size" in bad.stderr
+
+
+def test_c3d_solve_fails_loudly_without_gpu(built, tmp_path):
+    """Error convention of the reference's job.sh (:281-283): non-zero exit + iam.failed."""
+    from chromosome3d_amd import lib
+    if lib.load().c3d_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    out = subprocess.run([os.path.join(LIBDIR, "c3d_solve"), "--if", MATRIX, "--out", str(tmp_path), "-m", "2"],
+                         capture_output=True, text=True)
+    assert out.returncode != 0
+    assert (tmp_path / "iam.failed").exists() and not (tmp_path / "iam.running").exists()
+    assert "no HIP device" in out.stderr
+
+
+@pytest.mark.gpu
+def test_c3d_solve_cli_end_to_end(built, tmp_path):
+    out = subprocess.run([os.path.join(LIBDIR, "c3d_solve"), "--if", MATRIX, "--out", str(tmp_path), "-m", "6"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    cid = "chr21_1mb_matrix"
+    assert hashlib.md5(open(tmp_path / "contact.tbl", "rb").read()).hexdigest() == G["chr21_1mb"]["md5_tbl"]
+    assert hashlib.md5(open(tmp_path / f"{cid}.dist", "rb").read()).hexdigest() == G["chr21_1mb"]["md5_dist"]
+    assert not (tmp_path / "iam.running").exists() and not (tmp_path / "iam.failed").exists()
+    pdbs = sorted(tmp_path.glob(f"{cid}_*.pdb"))
+    assert len(pdbs) == 6
+    # the same restraints through the cns_solve-shaped entry (--tbl) give the same models
+    t2 = tmp_path / "tbl_run"
+    out2 = subprocess.run([os.path.join(LIBDIR, "c3d_solve"), "--tbl", str(tmp_path / "contact.tbl"), "--n", "37",
+                           "--out", str(t2), "--id", cid, "-m", "6"], capture_output=True, text=True)
+    assert out2.returncode == 0, out2.stderr
+    for p in pdbs:
+        a = [l for l in open(p) if l.startswith("ATOM")]
+        b = [l for l in open(t2 / p.name) if l.startswith("ATOM")]
+        assert a == b
+    sc = subprocess.run([os.path.join(LIBDIR, "c3d_score"), MATRIX, str(tmp_path)], capture_output=True, text=True)
+    vals = [float(l.split("\t")[0]) for l in sc.stdout.strip().splitlines()[1:]]
+    assert len(vals) == 6 and all(-0.95 < v < -0.75 for v in vals)
+
+
+@pytest.mark.gpu
+def test_perl_driver_same_cli_and_outputs(built, tmp_path):
+    """chromosome3D.pl's interface: -i (and the -if spelling test.sh uses), -o, -k, -a, -m."""
+    if shutil.which("perl") is None:
+        pytest.skip("no perl on this box")
+    drv = os.path.join(ROOT, "bin", "chromosome3D_amd.pl")
+    for flag in ("-i", "-if"):
+        od = tmp_path / f"out{flag}"
+        out = subprocess.run(["perl", drv, flag, MATRIX, "-o", str(od), "-m", "7"], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        cid = "chr21_1mb_matrix"
+        for f in (f"{cid}.txt", f"{cid}.dist", f"{cid}.rr", "contact.tbl", "job.sh", "job.log", "model_info.log"):
+            assert (od / f).exists(), f
+        assert open(od / "contact.tbl", "rb").read() == open(os.path.join(GOLD, "chr21_1mb.contact.tbl"), "rb").read()
+        models = sorted(od.glob(f"{cid}_model*.pdb"))
+        assert [m.name for m in models] == [f"{cid}_model{k}.pdb" for k in range(1, 6)]
+        assert len(list(od.glob(f"{cid}_*.pdb"))) == 7
+        assert "Restraints : 528 lines in tbl file" in out.stdout and "model1.pdb <=" in out.stdout
+        # ranking = ascending int(REMARK noe)
+        e = []
+        for m in models:
+            v = [l for l in open(m) if l.startswith("REMARK noe")][0].replace(" ", "").split("=")[1]
+            e.append(int(float(v)))
+        assert e == sorted(e)
+        # satisfaction table rows "count/528  sumdev  name" agree with the library's assessment
+        from chromosome3d_amd import pipeline
+        rows = pipeline.read_tbl(str(od / "contact.tbl"))
+        tab = [l.split() for l in out.stdout.splitlines() if "/528" in l]
+        assert len(tab) == 7
+        name_to_row = {t[2]: t for t in tab}
+        x = pipeline.read_pdb_ca(str(models[0]))
+        first = [l for l in out.stdout.splitlines() if l.startswith("model1.pdb <=")][0].split("<=")[1].strip()
+        sat, dev = pipeline.assess(x, rows)
+        t = name_to_row[os.path.basename(first)[:-4]]
+        assert t[0] == f"{sat}/528" and t[1] == "%.2f" % dev
+    # bad usage -> non-zero exit like the reference's print_usage / confess
+    assert subprocess.run(["perl", drv, "-o", str(tmp_path / "x")], capture_output=True).returncode != 0
+    assert subprocess.run(["perl", drv, "-i", "/nonexistent.txt", "-o", str(tmp_path / "x")], capture_output=True).returncode != 0

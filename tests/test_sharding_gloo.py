@@ -1,0 +1,72 @@
+"""Replica sharding + the final gather for ranking on 2 ranks (gloo, CPU): the N>1 path of
+bench.py / the batch driver.  Uses the same code as the GPU run (chromosome3d_amd.sharding)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from chromosome3d_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_replica_ranges_cover_exactly():
+    for total, world in [(20, 1), (20, 2), (20, 4), (20, 8), (7, 3), (3, 8)]:
+        got = [sharding.replica_range(total, world, r) for r in range(world)]
+        ids = [i for s, c in got for i in range(s, s + c)]
+        assert ids == list(range(total))
+        assert max(c for _, c in got) - min(c for _, c in got) <= 1
+    assert [c for _, c in (sharding.replica_range(20, 8, r) for r in range(8))] == [3, 3, 3, 3, 2, 2, 2, 2]
+
+
+def test_lpt_assignment_balances_config4():
+    # restraint counts of the 22 available 500 kb matrices
+    R = [101426, 74211, 69222, 61066, 55278, 47269, 39871, 26525, 34191, 33670, 33153, 17578, 14704, 12874, 11935,
+         11628, 10585, 5886, 6670, 2328, 2140, 45150]
+    parts = sharding.lpt_assign(R, 8)
+    assert sorted(k for p in parts for k in p) == list(range(len(R)))
+    loads = [sum(R[k] for k in p) for p in parts]
+    assert max(loads) <= max(R) * 1.05 or max(loads) / (sum(R) / 8) < 1.25
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 11
+        start, count = sharding.replica_range(5, world, rank)        # 5 replicas over 2 ranks: 3 + 2
+        rng = np.random.default_rng(100)
+        e_all = rng.uniform(1e4, 2e4, size=5)
+        x_all = rng.normal(size=(5, n, 3))
+        ids = np.arange(start, start + count)
+        rec = sharding.pack_records(ids, e_all[ids], -0.8 - 0.01 * ids, x_all[ids])
+        allrec = sharding.gather_records(rec)
+        order = sharding.rank_models(allrec)
+        q.put((rank, allrec[:, 0].tolist(), allrec[:, 1].tolist(), order, float(np.abs(allrec[:, 4:].reshape(5, n, 3) - x_all).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_and_rank_world2():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in range(2)]
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    rng = np.random.default_rng(100)
+    e_all = rng.uniform(1e4, 2e4, size=5)
+    expect = sorted(range(5), key=lambda k: (int(e_all[k]), k))
+    for rank, ids, e, order, err in res:
+        assert ids == [0.0, 1.0, 2.0, 3.0, 4.0]           # every rank sees all replicas, ordered by id
+        assert np.allclose(e, e_all) and err == 0.0
+        assert order == expect                              # identical ranking on every rank
