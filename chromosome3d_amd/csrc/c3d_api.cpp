@@ -318,8 +318,8 @@ extern "C" void c3d_default_model(c3d_model* m) {
     m->min_sep = 5; m->noe_pot = 1; m->rep_sep = 2; m->ang_mode = 1;
     m->s_noe = 10.0f; m->rswitch = 1.0f; m->asym = 2.0f;
     m->k_bond = 700.0f; m->b0 = 3.8f;
-    m->k_ang = 60.0f; m->a0 = 7.4f;
-    m->r0_rep = 6.0f; m->k_rep = 1.0f;
+    m->k_ang = 80.0f; m->a0 = 7.4f;
+    m->r0_rep = 6.75f; m->k_rep = 1.0f;
     m->mass = 100.0f; m->fbeta = 10.0f;
 }
 extern "C" void c3d_default_fire(c3d_fire_params* f) {

@@ -22,7 +22,7 @@ static void usage() {
     fprintf(stderr,
             "usage: c3d_solve (--if <IF matrix> | --tbl <contact.tbl> --n <beads>) --out <dir> [--id <ID>]\n"
             "                 [-k <K=11>] [-a <alpha=0.5>] [-m <models=20>] [--seed <82364>] [--first-replica <0>]\n"
-            "                 [--device <0>] [--min-steps <3000>] [--gtol <1e-3>] [--no-graph] [--quiet]\n");
+            "                 [--device <0>] [--min-steps <3000>] [--gtol <1e-2>] [--no-graph] [--quiet]\n");
 }
 
 #define CHECK(call)                                                              \
@@ -45,7 +45,7 @@ static int fail_exit(const std::string& out_dir) {
 
 int main(int argc, char** argv) {
     std::string if_path, tbl_path, out_dir, id;
-    double K = 11, alpha = 0.5, gtol = 1e-3;
+    double K = 11, alpha = 0.5, gtol = 1e-2;
     int models = 20, device = 0, n_beads = 0, min_steps = 3000, use_graph = 1, quiet = 0;
     unsigned long long seed = 82364ULL;
     unsigned first_rep = 0;

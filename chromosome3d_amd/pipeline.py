@@ -116,7 +116,7 @@ def spearman_IF_pdb(IF, xyz, rng=3):
 
 
 def build_models(solver, model_count=MODELCOUNT, seed=MD_SEED, first_replica=0, model=None, stages=None, fire=None,
-                 gtol=1e-3, check_every=250):
+                 gtol=1e-2, check_every=250):
     """The replacement of `cns_solve < dgsa.inp` (:254-289): runs the whole annealing schedule
     for model_count replicas on the GPU and returns (xyz [M,N,3], energies [M,3])."""
     solver.set_model(model if model is not None else default_model())

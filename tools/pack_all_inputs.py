@@ -1,0 +1,15 @@
+"""Pack every bundled reference matrix + model into tests/golden/_all/ (git-ignored, travels with
+gpurun snapshots) for the all-chromosome parity sweep.  Runs only where /root/reference exists."""
+import glob, os, shutil, sys
+import numpy as np
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "_all")
+os.makedirs(OUT, exist_ok=True)
+for p in sorted(glob.glob(f"{REF}/input/*_matrix.txt")):
+    cid = os.path.basename(p)[:-len("_matrix.txt")]
+    m = np.array([[float(t) for t in l.split()] for l in open(p) if l.strip()])
+    assert np.array_equal(m, m.T), cid
+    np.savez_compressed(f"{OUT}/{cid}_upper.npz", n=m.shape[0], upper=m[np.triu_indices(m.shape[0])])
+    for q in glob.glob(f"{REF}/output_models/{cid}_rank*_a11.pdb"):
+        shutil.copyfile(q, f"{OUT}/{os.path.basename(q)}")
+print("packed", len(glob.glob(f"{OUT}/*.npz")), "matrices")
