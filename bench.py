@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
+    ap.add_argument("--groups", type=int, default=0, help="replica groups on separate streams (0 = library default)")
     ap.add_argument("--rpw", type=int, default=0, help="rows per wave of the step kernel (tuning knob; 0 = library default)")
     args = ap.parse_args()
 
@@ -101,6 +102,8 @@ def main():
     s.set_option("use_graph", 0 if args.no_graph else 1)
     if args.rpw:
         s.set_option("rows_per_wave", args.rpw)
+    if args.groups:
+        s.set_option("replica_groups", args.groups)
     L = s.schedule_length
 
     def sync_all():

@@ -72,7 +72,12 @@ void normals4(uint64_t seed, uint32_t replica, uint32_t bead, uint32_t purpose, 
 
 struct c3d_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // group 0 / everything that is not a step launch
+    static constexpr int kMaxGroups = 4;
+    int ngroups = 2;                       // replica groups stepped on separate streams (overlap latency phases)
+    hipStream_t gstream[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t gev[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     int n = 0, npad = 0, ntiles = 0, nrep = 0, R = 0;
@@ -96,7 +101,7 @@ struct c3d_ctx {
     size_t pc = 0;
     int parity = 0;
     long steps_done = 0;
-    std::map<std::tuple<long, int, int>, hipGraphExec_t> graphs;
+    std::map<std::tuple<long, int, int, int>, hipGraphExec_t> graphs;
 
     double last_ms = 0;
     long last_steps = 0, last_launches = 0;
@@ -131,9 +136,10 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
     c3d::DevModel m{};
     const c3d_model& h = c->model;
     m.n = c->n; m.npad = c->npad; m.ntiles = c->ntiles; m.nrep = c->nrep;
+    m.rep_base = 0; m.nrep_g = c->nrep;
     m.rpw = c->rpw;
     m.stage_dma = c->stage_dma;
-    m.noe_pot = h.noe_pot; m.ang_mode = h.ang_mode;
+    m.noe_pot = h.noe_pot; m.ang_mode = h.ang_mode; m.rep_sep = h.rep_sep;
     m.rs = h.rswitch;
     m.tail_c = h.asym * h.rswitch;
     m.tail_b = (m.tail_c - 2.0f * h.rswitch) * h.rswitch * h.rswitch;
@@ -220,23 +226,42 @@ void unpack(const c3d_ctx* c, const std::vector<float>& soa, float* aos) {
     }
 }
 
-int launch_op(c3d_ctx* c, const Op& op) {
-    const c3d::DevModel m = dev_model(c);
-    hipError_t e = c3d::launch_step(m, op.p, dev_fire(c), c->buf, c->parity, general_tail(m), c->stream);
+void group_range(const c3d_ctx* c, int g, int& base, int& count) {
+    const int G = std::min(c->ngroups, std::max(c->nrep, 1));
+    const int q = c->nrep / G, r = c->nrep % G;
+    base = g * q + std::min(g, r);
+    count = q + (g < r ? 1 : 0);
+}
+int active_groups(const c3d_ctx* c) { return std::min(c->ngroups, std::max(c->nrep, 1)); }
+
+// one SA-step launch for replica group g, reading parity `par`
+int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
+    c3d::DevModel m = dev_model(c);
+    group_range(c, g, m.rep_base, m.nrep_g);
+    hipError_t e = c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, general_tail(m), c->gstream[g]);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
-    c->parity ^= 1;
     return C3D_OK;
 }
 
-// run program ops [pc, pc + nops): eager or via cached graphs
+// run program ops [pc, pc + nops): eager or via cached graphs; every replica group advances on its
+// own stream (fork from / join into stream 0 around the call)
 int run_ops(c3d_ctx* c, size_t nops) {
+    const int G = active_groups(c);
+    if (G > 1) {
+        HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
+        for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(c->gstream[g], c->fork_ev, 0));
+    }
     size_t done = 0;
     while (done < nops) {
         const size_t chunk = std::min<size_t>(nops - done, c->use_graph ? (size_t)c->graph_chunk : nops - done);
         if (!c->use_graph || chunk < 8) {
-            for (size_t k = 0; k < chunk; ++k) {
-                int rc = launch_op(c, c->program[c->pc + k]);
-                if (rc) return rc;
+            for (int g = 0; g < G; ++g) {
+                int par = c->parity;
+                for (size_t k = 0; k < chunk; ++k) {
+                    int rc = launch_op(c, c->program[c->pc + k], g, par);
+                    if (rc) return rc;
+                    par ^= 1;
+                }
             }
         } else {
             // homogeneous FIRE ranges (same stage, all kind 2) share one graph regardless of pc
@@ -244,32 +269,37 @@ int run_ops(c3d_ctx* c, size_t nops) {
             const Op& last = c->program[c->pc + chunk - 1];
             long sig = (long)c->pc;
             if (first.p.kind == 2 && last.p.kind == 2 && first.stage == last.stage) sig = -(long)(first.stage + 1);
-            const auto key = std::make_tuple(sig, (int)chunk, c->parity);
-            auto it = c->graphs.find(key);
-            if (it == c->graphs.end()) {
-                hipGraph_t g = nullptr;
-                HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                const int p0 = c->parity;
-                int rc = C3D_OK;
-                for (size_t k = 0; k < chunk && rc == C3D_OK; ++k) rc = launch_op(c, c->program[c->pc + k]);
-                hipError_t ce = hipStreamEndCapture(c->stream, &g);
-                c->parity = p0;
-                if (rc) { if (g) hipGraphDestroy(g); return rc; }
-                if (ce != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-                hipGraphExec_t ge = nullptr;
-                hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-                hipGraphDestroy(g);
-                if (ie != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
-                it = c->graphs.emplace(key, ge).first;
+            for (int g = 0; g < G; ++g) {
+                const auto key = std::make_tuple(sig, (int)chunk, c->parity, g);
+                auto it = c->graphs.find(key);
+                if (it == c->graphs.end()) {
+                    hipGraph_t gr = nullptr;
+                    HIP_TRY(hipStreamBeginCapture(c->gstream[g], hipStreamCaptureModeThreadLocal));
+                    int par = c->parity;
+                    int rc = C3D_OK;
+                    for (size_t k = 0; k < chunk && rc == C3D_OK; ++k) { rc = launch_op(c, c->program[c->pc + k], g, par); par ^= 1; }
+                    hipError_t ce = hipStreamEndCapture(c->gstream[g], &gr);
+                    if (rc) { if (gr) hipGraphDestroy(gr); return rc; }
+                    if (ce != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+                    hipGraphExec_t ge = nullptr;
+                    hipError_t ie = hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0);
+                    hipGraphDestroy(gr);
+                    if (ie != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+                    it = c->graphs.emplace(key, ge).first;
+                }
+                HIP_TRY(hipGraphLaunch(it->second, c->gstream[g]));
             }
-            HIP_TRY(hipGraphLaunch(it->second, c->stream));
-            if (chunk & 1) c->parity ^= 1;
         }
+        if (chunk & 1) c->parity ^= 1;
         for (size_t k = 0; k < chunk; ++k)
             if (c->program[c->pc + k].counted) { ++c->steps_done; ++c->last_steps; }
         c->last_launches += (long)chunk;
         c->pc += chunk;
         done += chunk;
+    }
+    for (int g = 1; g < G; ++g) {
+        HIP_TRY(hipEventRecord(c->gev[g], c->gstream[g]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->gev[g], 0));
     }
     return C3D_OK;
 }
@@ -373,8 +403,14 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     c3d_default_fire(&c->fire);
     c->stages.resize(c3d_default_schedule(nullptr, 0, 3000));
     c3d_default_schedule(c->stages.data(), (int)c->stages.size(), 3000);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+              hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
+    c->gstream[0] = c->stream;
+    for (int g = 1; ok && g < c3d_ctx::kMaxGroups; ++g)
+        ok = hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         delete c;
         return fail(C3D_ERR_HIP, "cannot create HIP stream/events");
     }
@@ -385,22 +421,27 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
 extern "C" void c3d_destroy(c3d_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    for (int g = 0; g < c3d_ctx::kMaxGroups; ++g) if (c->gstream[g]) hipStreamSynchronize(c->gstream[g]);
     drop_graphs(c);
     free_replica_buffers(c);
     if (c->buf.tgt) hipFree(c->buf.tgt);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    for (int g = 1; g < c3d_ctx::kMaxGroups; ++g) {
+        if (c->gstream[g]) hipStreamDestroy(c->gstream[g]);
+        if (c->gev[g]) hipEventDestroy(c->gev[g]);
+    }
+    if (c->fork_ev) hipEventDestroy(c->fork_ev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
 extern "C" int c3d_set_model(c3d_ctx* c, const c3d_model* m) {
     if (!c || !m) return fail(C3D_ERR_INVALID, "c3d_set_model: null argument");
-    if (m->mass <= 0 || m->rswitch <= 0 || m->min_sep < 1 || m->rep_sep < 1 || m->noe_pot < 0 || m->noe_pot > 2)
+    if (m->mass <= 0 || m->rswitch <= 0 || m->min_sep < 1 || m->rep_sep < 1 || m->rep_sep > 3 || m->noe_pot < 0 || m->noe_pot > 2)
         return fail(C3D_ERR_INVALID, "c3d_set_model: parameter out of range");
-    if (c->have_targets && (m->min_sep != c->model.min_sep || m->rep_sep != c->model.rep_sep))
-        return fail(C3D_ERR_INVALID, "c3d_set_model: min_sep/rep_sep must be set before the targets are built");
+    if (c->have_targets && m->min_sep != c->model.min_sep)
+        return fail(C3D_ERR_INVALID, "c3d_set_model: min_sep must be set before the targets are built");
     c->model = *m;
     build_program(c);
     return C3D_OK;
@@ -425,6 +466,12 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
     if (!strcmp(key, "rows_per_wave")) {
         if (value != 1 && value != 2 && value != 4) return fail(C3D_ERR_INVALID, "rows_per_wave must be 1, 2 or 4");
         c->rpw = (int)value;
+        drop_graphs(c);
+        return C3D_OK;
+    }
+    if (!strcmp(key, "replica_groups")) {   // groups stepped concurrently on separate streams
+        if (value < 1 || value > c3d_ctx::kMaxGroups) return fail(C3D_ERR_INVALID, "replica_groups must be 1..4");
+        c->ngroups = (int)value;
         drop_graphs(c);
         return C3D_OK;
     }

@@ -36,22 +36,27 @@ __device__ unsigned long long g_stamps[16];
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
-// Wave64 sum on the VALU with DPP (no ds_bpermute / LDS crossbar round trips): 6 v_add_f32_dpp,
-// total in lane 63, broadcast through an SGPR (v_readlane).  gfx9 DPP controls:
-// quad_perm[a,b,c,d] = a|b<<2|c<<4|d<<6, row_mirror 0x140, row_half_mirror 0x141,
-// row_bcast:15 0x142 (row_mask 0xa), row_bcast:31 0x143 (row_mask 0xc).
-template <int CTRL, int ROW_MASK = 0xf>
+// Wave64 reductions on the VALU only (no ds_bpermute / LDS crossbar round trips):
+//   lanes ^1, ^2      v_add_f32_dpp quad_perm
+//   lanes -4, -8      v_add_f32_dpp row_ror:4 / row_ror:8   (sum of the 16-lane row, position kept)
+//   rows ^1, halves   v_permlane16_swap / v_permlane32_swap  (gfx950) + v_add
+// gfx9 DPP controls: quad_perm[a,b,c,d] = a|b<<2|c<<4|d<<6, row_ror:n = 0x120+n.
+template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_sum(float v) {
+__device__ __forceinline__ float xrow_sum(float v) {   // + the other three 16-lane rows, every lane
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float wave_sum(float v) {   // total in every lane
     v += dpp_mov<0xB1>(v);          // lanes ^1
     v += dpp_mov<0x4E>(v);          // lanes ^2
-    v += dpp_mov<0x141>(v);         // row_half_mirror
-    v += dpp_mov<0x140>(v);         // row_mirror
-    v += dpp_mov<0x142, 0xa>(v);    // row_bcast:15
-    v += dpp_mov<0x143, 0xc>(v);    // row_bcast:31
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    v += dpp_mov<0x124>(v);         // row_ror:4
+    v += dpp_mov<0x128>(v);         // row_ror:8
+    return xrow_sum(v);
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -65,12 +70,38 @@ __device__ __forceinline__ float quad_sum(float v) {
     if constexpr (RPW >= 4) v += dpp_mov<0x4E>(v);
     return v;
 }
-// uniform per-row values -> the value of row (lane & (RPW-1)) in each lane, plain selects
+// Transposing reduction: a[r] is this lane's partial sum for row r.  Returns, in every lane l, the
+// sum over all 64 lanes of a[l & (RPW-1)]: the row selection rides on the first butterfly levels
+// (lane parity picks which row a lane keeps), every later level preserves lane & 3.
 template <int RPW>
-__device__ __forceinline__ float row_select(const float (&a)[RPW], int lane) {
-    if constexpr (RPW == 1) return a[0];
-    else if constexpr (RPW == 2) return (lane & 1) ? a[1] : a[0];
-    else return (lane & 2) ? ((lane & 1) ? a[3] : a[2]) : ((lane & 1) ? a[1] : a[0]);
+__device__ __forceinline__ float reduce_rows(const float (&a)[RPW], int lane) {
+    static_assert(RPW == 1 || RPW == 2 || RPW == 4, "rows per wave must be 1, 2 or 4");
+    float k;
+    if constexpr (RPW == 1) {
+        k = a[0];
+        k += dpp_mov<0xB1>(k);
+        k += dpp_mov<0x4E>(k);
+    } else if constexpr (RPW == 2) {
+        const bool b0 = lane & 1;
+        k = b0 ? a[1] : a[0];
+        const float s = b0 ? a[0] : a[1];
+        k += dpp_mov<0xB1>(s);
+        k += dpp_mov<0x4E>(k);
+    } else {
+        const bool b0 = lane & 1, b1 = lane & 2;
+        float k01 = b0 ? a[1] : a[0];
+        const float s01 = b0 ? a[0] : a[1];
+        float k23 = b0 ? a[3] : a[2];
+        const float s23 = b0 ? a[2] : a[3];
+        k01 += dpp_mov<0xB1>(s01);
+        k23 += dpp_mov<0xB1>(s23);
+        k = b1 ? k23 : k01;
+        const float s = b1 ? k01 : k23;
+        k += dpp_mov<0x4E>(s);
+    }
+    k += dpp_mov<0x124>(k);
+    k += dpp_mov<0x128>(k);
+    return xrow_sum(k);
 }
 
 // XCD-aware block -> (tile, replica) map.  Blocks b and b+8 share an XCD (round-robin dispatch,
@@ -79,11 +110,11 @@ __device__ __forceinline__ float row_select(const float (&a)[RPW], int lane) {
 __device__ __forceinline__ bool block_to_tile(const DevModel& m, int& tile, int& rep) {
     const int b = blockIdx.x;
     const int k = b >> 3;
-    rep = k % m.nrep;
-    tile = (k / m.nrep) * 8 + (b & 7);
+    rep = m.rep_base + k % m.nrep_g;
+    tile = (k / m.nrep_g) * 8 + (b & 7);
     return tile < m.ntiles;
 }
-inline int grid_blocks(const DevModel& m) { return 8 * ((m.ntiles + 7) / 8) * m.nrep; }
+inline int grid_blocks(const DevModel& m) { return 8 * ((m.ntiles + 7) / 8) * m.nrep_g; }
 
 template <int POT, bool GEN>
 __device__ __forceinline__ float noe_grad(float delta, const DevModel& m) {
@@ -123,11 +154,11 @@ __device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, f
     const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
     const float rinv = __builtin_amdgcn_rsqf(r2);
     const float d = r2 * rinv;
-    const float t = fabsf(v);
-    const float g = noe_grad<POT, GEN>(d - t, m);
-    float c = (t > 0.0f) ? -p.w_noe * g * rinv : 0.0f;
-    const float q = fmaxf(p.rep_r2 - r2, 0.0f);
-    c += (__float_as_int(v) >= 0) ? p.w_rep4 * q : 0.0f;
+    const float g = noe_grad<POT, GEN>(d - v, m);
+    float c = (v > 0.0f) ? -p.w_noe * g * rinv : 0.0f;   // v = target (A), 0 = no restraint
+    // repel on EVERY column: padding beads are 1e4 A away (q = 0), the self term has dx = 0, and the
+    // |i-j| < rep_sep neighbours are taken back out in the chain-term pass below
+    c = fmaf(p.w_rep4, fmaxf(p.rep_r2 - r2, 0.0f), c);
     fx = fmaf(c, dx, fx);
     fy = fmaf(c, dy, fy);
     fz = fmaf(c, dz, fz);
@@ -164,35 +195,39 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
 #pragma unroll
         for (int r = 0; r < RPW; ++r) tv[r] = tn[r];
     }
-    // chain terms: pseudo-bond (i,i+-1) and pseudo-angle (i,i+-2), lanes 0..3 take one neighbour each
+    // chain terms: pseudo-bond (i,i+-1), pseudo-angle (i,i+-2) and the repel take-back for
+    // |i-j| < rep_sep.  Lane l < 4*RPW handles neighbour (l & 3) of row (l >> 2) — one pass for all rows.
     {
-        const int off = lane < 2 ? lane - 2 : lane - 1;   // -2,-1,+1,+2 for lanes 0..3
+        const int nb = lane & 3;
+        const int off = nb < 2 ? nb - 2 : nb - 1;          // -2,-1,+1,+2
         const int sep = off < 0 ? -off : off;
+        const int rsel = lane >> 2;                          // row of this lane (valid while lane < 4*RPW)
+        const int row = min(row0 + rsel, m.n - 1);
+        const int jn = row + off;
+        float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+        if (lane < 4 * RPW && row0 + rsel < m.n && jn >= 0 && jn < m.n) {
+            const float dx = xs[row] - xs[jn], dy = ys[row] - ys[jn], dz = zs[row] - zs[jn];
+            const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
+            const float rinv = __builtin_amdgcn_rsqf(r2);
+            const float d = r2 * rinv;
+            const float k2 = sep == 1 ? m.k_bond2 : m.k_ang2;
+            const float r0 = sep == 1 ? m.b0 : m.a0;
+            const bool on = sep == 1 || (m.k_ang2 > 0.0f && (m.ang_mode == 1 || d < m.a0));
+            float c = on ? -p.w_all * k2 * (d - r0) * rinv : 0.0f;
+            if (sep < m.rep_sep) c -= p.w_rep4 * fmaxf(p.rep_r2 - r2, 0.0f);
+            cx = c * dx; cy = c * dy; cz = c * dz;
+        }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const int row = min(row0 + r, m.n - 1);
-            const int jn = row + off;
-            if (lane < 4 && jn >= 0 && jn < m.n) {
-                const float dx = xi[r] - xs[jn], dy = yi[r] - ys[jn], dz = zi[r] - zs[jn];
-                const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
-                const float rinv = __builtin_amdgcn_rsqf(r2);
-                const float d = r2 * rinv;
-                const float k2 = sep == 1 ? m.k_bond2 : m.k_ang2;
-                const float r0 = sep == 1 ? m.b0 : m.a0;
-                const bool on = sep == 1 || (m.k_ang2 > 0.0f && (m.ang_mode == 1 || d < m.a0));
-                const float c = on ? -p.w_all * k2 * (d - r0) * rinv : 0.0f;
-                fx[r] = fmaf(c, dx, fx[r]);
-                fy[r] = fmaf(c, dy, fy[r]);
-                fz[r] = fmaf(c, dz, fz[r]);
-            }
+            const bool mine = rsel == r;
+            fx[r] += mine ? cx : 0.0f;
+            fy[r] += mine ? cy : 0.0f;
+            fz[r] += mine ? cz : 0.0f;
         }
     }
-    float sx[RPW], sy[RPW], sz[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) { sx[r] = wave_sum(fx[r]); sy[r] = wave_sum(fy[r]); sz[r] = wave_sum(fz[r]); }
-    Fx = row_select<RPW>(sx, lane);
-    Fy = row_select<RPW>(sy, lane);
-    Fz = row_select<RPW>(sz, lane);
+    Fx = reduce_rows<RPW>(fx, lane);
+    Fy = reduce_rows<RPW>(fy, lane);
+    Fz = reduce_rows<RPW>(fz, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -203,7 +238,7 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
 //      previous step's partial sums, own-row velocities, the bead coordinates
 //   2. each WAVE reduces the partial sums itself (no barrier), coordinates go to LDS, ONE barrier
 //   3. pair loop with the target loads pipelined one block ahead
-//   4. lanes 0..RPW-1 finish one row each and store this wave's partial sums (no second barrier)
+//   4. lanes 0..RPW-1 finish one row each; tile partial sums through LDS
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 wave_sum4(float4 a) {
     return make_float4(wave_sum(a.x), wave_sum(a.y), wave_sum(a.z), wave_sum(a.w));
@@ -503,7 +538,7 @@ __global__ __launch_bounds__(256) void k_energy(const DevModel m, const float s_
             double r2 = dx * dx + dy * dy + dz * dz;
             if (r2 < 1e-12) r2 = 1e-12;
             const float v = tgt[(size_t)i * m.npad + j];
-            const double t = fabsf(v);
+            const double t = v;
             const int sep = j - i;
             if (t > 0) {
                 const double delta = sqrt(r2) - t, ad = fabs(delta);
@@ -516,7 +551,7 @@ __global__ __launch_bounds__(256) void k_energy(const DevModel m, const float s_
                 const double d = sqrt(r2);
                 if (m.ang_mode == 1 || d < m.a0) { const double dl = d - m.a0; e_bond += 0.5 * m.k_ang2 * dl * dl; }
             }
-            if (__float_as_int(v) >= 0 && r2 < rep_r2) { const double q = rep_r2 - r2; e_rep += q * q; }
+            if (sep >= m.rep_sep && r2 < rep_r2) { const double q = rep_r2 - r2; e_rep += q * q; }
         }
     }
     red[0][tid] = e_noe * s_noe; red[1][tid] = e_bond; red[2][tid] = e_rep * k_rep;
@@ -618,11 +653,9 @@ __global__ __launch_bounds__(256) void k_if_quantise(const double* __restrict__ 
             dist10[(size_t)i * n + j] = t10;
             const int sep = i > j ? i - j : j - i;
             const bool noe = sep >= min_sep && t10 > 0;
-            const bool rep = sep >= rep_sep;
-            float t = noe ? (float)((double)t10 / 10.0) : 0.0f;
-            enc = rep ? t : __int_as_float(__float_as_int(t) | 0x80000000);
+            enc = noe ? (float)((double)t10 / 10.0) : 0.0f;
         } else {
-            enc = __int_as_float(0x80000000);   // -0.0f: padding column, no NOE, no repel
+            enc = 0.0f;   // padding column: no restraint (and the padding beads are far away)
         }
         tgt[(size_t)i * npad + j] = enc;
     }

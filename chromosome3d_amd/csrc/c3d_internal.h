@@ -15,14 +15,15 @@ constexpr int kRowsPerWave = 4;
 constexpr int kTileRows = kWaves * kRowsPerWave;
 constexpr int kBlock = kWaves * 64;
 
-// far-away coordinates for the padding beads j in [n, npad): no NOE (target -0.0f), no repel
+// far-away coordinates for the padding beads j in [n, npad): no NOE (target 0), repel term vanishes
 constexpr float kPadCoord = 1.0e4f;
 
 struct DevModel {
     int n, npad, ntiles, nrep;
+    int rep_base, nrep_g;          // replica group of this launch: [rep_base, rep_base + nrep_g)
     int stage_dma;                 // 1: coordinates staged with global_load_lds (async), 0: through registers
     int rpw;                       // rows per wave of the step kernel (1, 2 or 4); waves/WG = 16/rpw
-    int noe_pot, ang_mode;
+    int noe_pot, ang_mode, rep_sep;
     float rs, tail_c, tail_b;      // soft tail: dE/dD = tail_c - tail_b / D^2  (D > rs)
     float k_bond2, b0;             // 2*k_bond
     float k_ang2, a0;              // 2*k_ang
@@ -82,13 +83,7 @@ hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, 
                                double* scratchP, double* partial, int npartial, int32_t* dist10, float* tgt,
                                hipStream_t s);
 
-// Target encoding shared by host (c3d_set_restraints) and device (K1):
-//   |v| = NOE target in Angstrom (0 = no restraint); sign bit set = repel disabled for the pair.
-inline float encode_target_host(float t, bool repel_on) {
-    union { float f; uint32_t u; } c;
-    c.f = t > 0 ? t : 0.0f;
-    if (!repel_on) c.u |= 0x80000000u;
-    return c.f;
-}
+// Target matrix entry: NOE target in Angstrom, 0 = no restraint (host c3d_set_restraints and K1).
+inline float encode_target_host(float t, bool) { return t > 0 ? t : 0.0f; }
 
 }  // namespace c3d

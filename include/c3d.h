@@ -43,7 +43,7 @@ typedef struct c3d_ctx c3d_ctx;
 typedef struct {
     int32_t min_sep;   /* 5: restraints only for |i-j| >= min_sep                        */
     int32_t noe_pot;   /* 0 symmetric soft-square, 1 X-PLOR soft-square (default), 2 square */
-    int32_t rep_sep;   /* repel acts on |i-j| >= rep_sep                                 */
+    int32_t rep_sep;   /* repel acts on |i-j| >= rep_sep (1..3)                          */
     int32_t ang_mode;  /* (i,i+2) term: 0 lower bound only, 1 harmonic                   */
     float s_noe;       /* NOE scale = con_wt = 10                                        */
     float rswitch;     /* 1.0                                                            */
