@@ -66,7 +66,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=174)
+    ap.add_argument("--warmup", type=int, default=172)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
@@ -191,7 +191,7 @@ def main():
             "dtype": "f32",
             "data": "bundled Hi-C matrix chr1_500kb (tests/golden/inputs, exact float64 upper triangle); random-coil starts, seed 82364",
             "config": {"workload": f"{WORKLOAD}: N={n} beads, R={R} restraints, {M} replicas per GPU, default schedule "
-                                   f"(201 FIRE + 1000 hot MD + 972 cool MD + {MIN_STEPS + 1} FIRE = {L} SA steps)",
+                                   f"(200 FIRE + 1000 hot MD + 972 cool MD + {MIN_STEPS} FIRE = {L} SA steps)",
                        "replicas_per_gpu": M, "parallelism": f"replica-sharded x{world}",
                        "launch": "eager" if args.no_graph else "hipGraph"},
             "wall_s_per_chromosome_20_replicas": round(L * wall / args.steps, 4),

@@ -115,10 +115,9 @@ void free_replica_buffers(c3d_ctx* c) {
     for (int k = 0; k < 2; ++k) {
         if (c->buf.X[k]) hipFree(c->buf.X[k]);
         if (c->buf.V[k]) hipFree(c->buf.V[k]);
-        if (c->buf.F[k]) hipFree(c->buf.F[k]);
         if (c->buf.P[k]) hipFree(c->buf.P[k]);
         if (c->buf.S[k]) hipFree(c->buf.S[k]);
-        c->buf.X[k] = c->buf.V[k] = c->buf.F[k] = c->buf.P[k] = nullptr;
+        c->buf.X[k] = c->buf.V[k] = c->buf.P[k] = nullptr;
         c->buf.S[k] = nullptr;
     }
     if (c->buf.Vinit) hipFree(c->buf.Vinit);
@@ -177,9 +176,8 @@ void build_program(c3d_ctx* c) {
     for (size_t s = 0; s < c->stages.size(); ++s) {
         const c3d_stage& st = c->stages[s];
         if (st.kind == 2) {
-            c->program.push_back({dev_step(c, 3, 0.0f, st.w_all, st.w_vdw, st.repel_s, 0.0f), (int)s, true});
-            for (int k = 0; k < st.nsteps; ++k)
-                c->program.push_back({dev_step(c, 2, 0.0f, st.w_all, st.w_vdw, st.repel_s, 0.0f), (int)s, true});
+            for (int k = 0; k < st.nsteps; ++k)   // kind 3 = first step of the stage (fresh FIRE state)
+                c->program.push_back({dev_step(c, k == 0 ? 3 : 2, 0.0f, st.w_all, st.w_vdw, st.repel_s, 0.0f), (int)s, true});
         } else {
             if (prev_kind == 2 || prev_kind == -1)
                 c->program.push_back({dev_step(c, 4, 0.0f, st.w_all, st.w_vdw, st.repel_s, st.t_bath), (int)s, false});
@@ -568,7 +566,6 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
         for (int k = 0; k < 2; ++k) {
             HIP_TRY(hipMalloc(&c->buf.X[k], sizeof(float) * nf));
             HIP_TRY(hipMalloc(&c->buf.V[k], sizeof(float) * nf));
-            HIP_TRY(hipMalloc(&c->buf.F[k], sizeof(float) * nf));
             HIP_TRY(hipMalloc(&c->buf.P[k], sizeof(float) * 4 * (size_t)nrep * c->ntiles * c3d::kTileRows));
             HIP_TRY(hipMalloc(&c->buf.S[k], sizeof(c3d::FireState) * nrep));
         }
@@ -617,7 +614,6 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
     HIP_TRY(hipMemcpy(c->buf.Vinit, soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMemset(c->buf.V[k], 0, sizeof(float) * nf));
-        HIP_TRY(hipMemset(c->buf.F[k], 0, sizeof(float) * nf));
         HIP_TRY(hipMemset(c->buf.P[k], 0, sizeof(float) * 4 * (size_t)nrep * c->ntiles * c3d::kTileRows));
         HIP_TRY(hipMemset(c->buf.S[k], 0, sizeof(c3d::FireState) * nrep));
     }
@@ -709,8 +705,7 @@ extern "C" int c3d_run(c3d_ctx* c) {
     rc = run_ops(c, nfixed);
     if (rc) return rc;
     if (early) {
-        // FIRE begin + chunks of check_every steps until every replica's RMS force < gtol
-        if (c->pc < c->program.size()) { rc = run_ops(c, 1); if (rc) return rc; }
+        // chunks of check_every steps until every replica's RMS force < gtol
         while (c->pc < c->program.size()) {
             const size_t chunk = std::min<size_t>((size_t)(c->check_every & ~1), c->program.size() - c->pc);
             rc = run_ops(c, chunk);

@@ -232,7 +232,7 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
 
 // ---------------------------------------------------------------------------------------------
 // K3/K4: one SA step (MD leap-frog or FIRE) for all replicas.
-// Workgroup = kTileRows / RPW waves; LDS: xs[npad] ys[npad] zs[npad] | vown[3][kTileRows].
+// Workgroup = kTileRows / RPW waves; LDS: xs[npad] ys[npad] zs[npad] | wpart[WAVES][4].
 // Latency plan of one workgroup (the kernel is latency-, not bandwidth-bound at N ~ 500):
 //   1. issue every independent global load up front: first target block of the wave's rows, the
 //      previous step's partial sums, own-row velocities, the bead coordinates
@@ -258,9 +258,9 @@ __device__ __forceinline__ void lds_dma_copy(const float* __restrict__ src, floa
 template <int POT, bool GEN, int RPW>
 __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     const float* __restrict__ pin, const float* __restrict__ xin, const float* __restrict__ tgt,
-    const float* __restrict__ vin, const float* __restrict__ fin, const float* __restrict__ vinit,
-    const FireState* __restrict__ sin, float* __restrict__ xout, float* __restrict__ vout, float* __restrict__ fout,
-    float* __restrict__ pout, FireState* __restrict__ sout, const DevModel m, const DevStep p, const DevFire fp) {
+    const float* __restrict__ vin, const float* __restrict__ vinit, const FireState* __restrict__ sin,
+    float* __restrict__ xout, float* __restrict__ vout, float* __restrict__ pout, FireState* __restrict__ sout,
+    const DevModel m, const DevStep p, const DevFire fp) {
     constexpr int WAVES = kTileRows / RPW;
     constexpr int BLOCK = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -272,11 +272,9 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     float* xs = smem;
     float* ys = smem + npad;
     float* zs = smem + 2 * npad;
-    float* vown = smem + 3 * npad;              // [3][kTileRows]
-    float* wpart = vown + 3 * kTileRows;        // [WAVES][4]
+    float* wpart = smem + 3 * npad;             // [WAVES][4]
     const size_t roff = (size_t)rep * 3 * npad;
-    const int tile_row0 = tile * kTileRows;
-    const int row0 = tile_row0 + wave * RPW;
+    const int row0 = tile * kTileRows + wave * RPW;
     const int row = row0 + (lane & (RPW - 1));  // the row this lane finishes (lanes < RPW only)
     const bool finisher = lane < RPW && row < m.n;
     const size_t ix = roff + row, iy = ix + npad, iz = iy + npad;
@@ -284,19 +282,10 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
 
     // ---- 1. every independent global load is issued before anything waits -------------------
-    // coordinates: MD / begin kinds copy them straight into LDS (async DMA); FIRE updates them
-    // in registers first (below) and loads its first bead here
-    float bx = 0, by = 0, bz = 0, bvx = 0, bvy = 0, bvz = 0, bfx = 0, bfy = 0, bfz = 0;
-    if (p.kind != 2) {
-        if (m.stage_dma) lds_dma_copy<BLOCK>(xin + roff, smem, 3 * npad, tid);
-        else for (int b = 4 * tid; b < 3 * npad; b += 4 * BLOCK) *reinterpret_cast<float4*>(smem + b) = *reinterpret_cast<const float4*>(xin + roff + b);
-    } else if (tid < npad) {
-        bx = xin[roff + tid]; by = xin[roff + npad + tid]; bz = xin[roff + 2 * npad + tid];
-        bvx = vin[roff + tid]; bvy = vin[roff + npad + tid]; bvz = vin[roff + 2 * npad + tid];
-        bfx = fin[roff + tid]; bfy = fin[roff + npad + tid]; bfz = fin[roff + 2 * npad + tid];
-    }
+    if (m.stage_dma) lds_dma_copy<BLOCK>(xin + roff, smem, 3 * npad, tid);
+    else for (int b = 4 * tid; b < 3 * npad; b += 4 * BLOCK) *reinterpret_cast<float4*>(smem + b) = *reinterpret_cast<const float4*>(xin + roff + b);
     float4 psum = make_float4(0, 0, 0, 0);
-    if (needs_partials) {   // one float4 per tile; ntiles <= 64 for N <= 1024
+    if (needs_partials) {   // one float4 per tile; ntiles <= 64 for N <= 512
         const float4* pp = reinterpret_cast<const float4*>(pin) + (size_t)rep * m.ntiles;
         for (int t = lane; t < m.ntiles; t += 64) {
             const float4 q = pp[t];
@@ -306,29 +295,27 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     float4 tv[RPW];
     if (p.kind != 4) tile_prefetch<RPW>(m, tgt, row0, lane, 0, tv);
     float vx0 = 0.0f, vy0 = 0.0f, vz0 = 0.0f;
-    if (finisher && is_md) {
+    if (finisher && p.kind != 3) {
         const float* vsrc = p.kind == 4 ? vinit : vin;
         vx0 = vsrc[ix]; vy0 = vsrc[iy]; vz0 = vsrc[iz];
     }
     FireState st;
-    st.dt = 0.0f; st.alpha = 0.0f; st.npos = 0; st.pad = 0;
+    st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0;
     if (p.kind == 2) st = sin[rep];
     C3D_STAMP(1);
 
-    // ---- 2. scalars per wave (no barrier), FIRE bead update, coordinates in LDS ---------------
+    // ---- 2. scalars per wave (no barrier; every wave derives the same values) -----------------
     float lam = 1.0f, cmx = 0.0f, cmy = 0.0f, cmz = 0.0f;   // MD
-    if (needs_partials) {
-        psum = wave_sum4(psum);
-        if (is_md) {          // psum = (sum v^2, sum vx, sum vy, sum vz) of the previous half step
-            const float tprev = fmaxf(m.t_fac * psum.x, 1e-2f);
-            if (p.kind == 0) lam = sqrtf(fmaxf(1.0f + p.dt * m.fbeta * (p.t_bath / tprev - 1.0f), 0.0f));
-            else lam = sqrtf(p.t_bath / tprev);
-            cmx = psum.y * m.inv_n; cmy = psum.z * m.inv_n; cmz = psum.w * m.inv_n;
-        }
-    }
-    if (p.kind == 2) {
-        // FIRE (Bitzek et al. 2006): psum = (v.F, F.F, v.v).  Every wave derives the same new state.
-        float keep, mix;
+    float keep = 0.0f, mix = 0.0f;                           // FIRE
+    if (needs_partials) psum = wave_sum4(psum);
+    if (p.kind == 0 || p.kind == 1) {   // psum = (sum v^2, sum vx, sum vy, sum vz) of the previous half step
+        const float tprev = fmaxf(m.t_fac * psum.x, 1e-2f);
+        if (p.kind == 0) lam = sqrtf(fmaxf(1.0f + p.dt * m.fbeta * (p.t_bath / tprev - 1.0f), 0.0f));
+        else lam = sqrtf(p.t_bath / tprev);
+        cmx = psum.y * m.inv_n; cmy = psum.z * m.inv_n; cmz = psum.w * m.inv_n;
+    } else if (p.kind == 2 || p.kind == 3) {
+        // FIRE (Bitzek et al. 2006) with the power test on the previous step's sums
+        // psum = (v.F, F.F, v.v); kind 3 = first step of a stage: psum = 0, fresh state
         if (psum.x > 0.0f) {
             keep = 1.0f - st.alpha;
             mix = st.alpha * sqrtf(psum.z / fmaxf(psum.y, 1e-30f));
@@ -338,43 +325,11 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
             }
             st.npos += 1;
         } else {
-            keep = 0.0f; mix = 0.0f;
             st.alpha = fp.alpha_start;
             st.dt *= fp.f_dec;
             st.npos = 0;
         }
         if (tile == 0 && tid == 0) sout[rep] = st;
-        // update ALL beads (redundantly per workgroup: O(N) next to the O(16 N) pair work); own rows
-        // are written back.  v' = keep*v + mix*F + a*F ; x' = x + clamp(dt*v')
-        const float dt = st.dt, a = st.dt * m.acc;
-        for (int b = tid; b < npad; b += BLOCK) {
-            float x = bx, y = by, z = bz, vx = bvx, vy = bvy, vz = bvz;
-            const float fx = bfx, fy = bfy, fz = bfz;
-            const int bn = b + BLOCK;
-            if (bn < npad) {   // next bead of this thread in flight while this one is updated
-                bx = xin[roff + bn]; by = xin[roff + npad + bn]; bz = xin[roff + 2 * npad + bn];
-                bvx = vin[roff + bn]; bvy = vin[roff + npad + bn]; bvz = vin[roff + 2 * npad + bn];
-                bfx = fin[roff + bn]; bfy = fin[roff + npad + bn]; bfz = fin[roff + 2 * npad + bn];
-            }
-            if (b < m.n) {
-                vx = keep * vx + mix * fx; vy = keep * vy + mix * fy; vz = keep * vz + mix * fz;
-                vx = fmaf(a, fx, vx); vy = fmaf(a, fy, vy); vz = fmaf(a, fz, vz);
-                const float dxs = dt * vx, dys = dt * vy, dzs = dt * vz;
-                const float d2 = dxs * dxs + dys * dys + dzs * dzs;
-                const float sc = d2 > fp.max_step * fp.max_step ? fp.max_step * __builtin_amdgcn_rsqf(d2) : 1.0f;
-                x = fmaf(sc, dxs, x); y = fmaf(sc, dys, y); z = fmaf(sc, dzs, z);
-                const int lr = b - tile_row0;
-                if (lr >= 0 && lr < kTileRows) {
-                    vown[lr] = vx; vown[kTileRows + lr] = vy; vown[2 * kTileRows + lr] = vz;
-                    xout[roff + b] = x; xout[roff + npad + b] = y; xout[roff + 2 * npad + b] = z;
-                    vout[roff + b] = vx; vout[roff + npad + b] = vy; vout[roff + 2 * npad + b] = vz;
-                }
-            }
-            xs[b] = x; ys[b] = y; zs[b] = z;
-        }
-    } else if (p.kind == 3 && tile == 0 && tid == 0) {
-        FireState s0; s0.dt = fp.dt_start; s0.alpha = fp.alpha_start; s0.npos = 0; s0.pad = 0;
-        sout[rep] = s0;
     }
     C3D_STAMP(2);
     __syncthreads();
@@ -388,34 +343,35 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     // ---- 4. epilogue: lanes 0..RPW-1 finish one row each --------------------------------------
     float4 q = make_float4(0, 0, 0, 0);   // this lane's contribution to the tile's partial sums
     if (finisher) {
+        float vx, vy, vz, xn, yn, zn;
         if (is_md) {
-            float vx, vy, vz;
             if (p.kind == 4) {            // MD begin: take the Maxwell velocities, no move
                 vx = vx0; vy = vy0; vz = vz0;
-                xout[ix] = xs[row]; xout[iy] = ys[row]; xout[iz] = zs[row];
+                xn = xs[row]; yn = ys[row]; zn = zs[row];
             } else {
                 const float a = p.dt * m.acc;
                 vx = fmaf(a, Fx, lam * (vx0 - cmx));
                 vy = fmaf(a, Fy, lam * (vy0 - cmy));
                 vz = fmaf(a, Fz, lam * (vz0 - cmz));
-                xout[ix] = fmaf(p.dt, vx, xs[row]);
-                xout[iy] = fmaf(p.dt, vy, ys[row]);
-                xout[iz] = fmaf(p.dt, vz, zs[row]);
+                xn = fmaf(p.dt, vx, xs[row]);
+                yn = fmaf(p.dt, vy, ys[row]);
+                zn = fmaf(p.dt, vz, zs[row]);
             }
-            vout[ix] = vx; vout[iy] = vy; vout[iz] = vz;
             q = make_float4(vx * vx + vy * vy + vz * vz, vx, vy, vz);
         } else {
-            float vx = 0.0f, vy = 0.0f, vz = 0.0f;
-            if (p.kind == 2) {
-                const int lr = row - tile_row0;
-                vx = vown[lr]; vy = vown[kTileRows + lr]; vz = vown[2 * kTileRows + lr];
-            } else {                      // FIRE begin: v = 0, x unchanged
-                xout[ix] = xs[row]; xout[iy] = ys[row]; xout[iz] = zs[row];
-                vout[ix] = 0.0f; vout[iy] = 0.0f; vout[iz] = 0.0f;
-            }
-            fout[ix] = Fx; fout[iy] = Fy; fout[iz] = Fz;
-            q = make_float4(vx * Fx + vy * Fy + vz * Fz, Fx * Fx + Fy * Fy + Fz * Fz, vx * vx + vy * vy + vz * vz, 0.0f);
+            // sums of THIS evaluation for the next step's test, with the velocity that led here
+            q = make_float4(vx0 * Fx + vy0 * Fy + vz0 * Fz, Fx * Fx + Fy * Fy + Fz * Fz, vx0 * vx0 + vy0 * vy0 + vz0 * vz0, 0.0f);
+            const float a = st.dt * m.acc;
+            vx = fmaf(a, Fx, keep * vx0 + mix * Fx);
+            vy = fmaf(a, Fy, keep * vy0 + mix * Fy);
+            vz = fmaf(a, Fz, keep * vz0 + mix * Fz);
+            const float dxs = st.dt * vx, dys = st.dt * vy, dzs = st.dt * vz;
+            const float d2 = dxs * dxs + dys * dys + dzs * dzs;
+            const float sc = d2 > fp.max_step * fp.max_step ? fp.max_step * __builtin_amdgcn_rsqf(d2) : 1.0f;
+            xn = fmaf(sc, dxs, xs[row]); yn = fmaf(sc, dys, ys[row]); zn = fmaf(sc, dzs, zs[row]);
         }
+        xout[ix] = xn; xout[iy] = yn; xout[iz] = zn;
+        vout[ix] = vx; vout[iy] = vy; vout[iz] = vz;
     }
     q.x = quad_sum<RPW>(q.x); q.y = quad_sum<RPW>(q.y); q.z = quad_sum<RPW>(q.z); q.w = quad_sum<RPW>(q.w);
     // tile partial sums: fixed-order sum over the waves (deterministic)
@@ -437,15 +393,14 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
 hipError_t read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16); }
 #endif
 
-static size_t step_lds_bytes(const DevModel& m) { return sizeof(float) * ((size_t)3 * m.npad + 3 * kTileRows + 4 * kTileRows); }
+static size_t step_lds_bytes(const DevModel& m) { return sizeof(float) * ((size_t)3 * m.npad + 4 * kTileRows); }
 
 template <int POT, bool GEN, int RPW>
 static hipError_t launch_step_r(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
                                 hipStream_t s) {
     const int q = par ^ 1;
     hipLaunchKernelGGL((k_step<POT, GEN, RPW>), dim3(grid_blocks(m)), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
-                       b.P[par], b.X[par], b.tgt, b.V[par], b.F[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.F[q], b.P[q],
-                       b.S[q], m, p, fp);
+                       b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
     return hipGetLastError();
 }
 template <int POT, bool GEN>

@@ -34,7 +34,7 @@ struct DevModel {
 };
 
 struct DevStep {
-    int kind;        // 0 MD T-coupling, 1 MD velocity rescale, 2 FIRE step, 3 FIRE begin, 4 MD begin
+    int kind;        // 0 MD T-coupling, 1 MD velocity rescale, 2 FIRE step, 3 first FIRE step of a stage, 4 MD begin
     float dt;
     float w_all;     // weights * w
     float w_noe;     // w_all * s_noe
@@ -55,7 +55,7 @@ struct FireState {   // per replica, double buffered
 
 // All device pointers of one context.  Layouts (npad = n rounded up to 256, one column block):
 //   tgt   [n][npad]            encoded restraint target (see encode_target)
-//   X,V,F [2][nrep][3][npad]   SoA coordinates / velocities / forces, double buffered by step parity
+//   X,V   [2][nrep][3][npad]   SoA coordinates / velocities, double buffered by step parity
 //   Vinit [nrep][3][npad]
 //   P     [2][nrep][ntiles][4] per-tile partial sums
 //   S     [2][nrep]            FIRE state
@@ -63,7 +63,6 @@ struct DevBuffers {
     float* tgt;
     float* X[2];
     float* V[2];
-    float* F[2];
     float* Vinit;
     float* P[2];
     FireState* S[2];

@@ -419,16 +419,20 @@ void c3o_md_step(const c3o_model* m, const int32_t* tgt10, const c3o_stage* st, 
         }
 }
 
-/* one FIRE step: expects F = F(x) on entry (the previous evaluation), leaves F = F(x_new).
- * Semantics follow the velocity-mixing / adaptive-dt rules of Bitzek et al. 2006 with a
- * per-bead displacement clamp. */
+/* one FIRE step in the form the device runs it (one force evaluation, one launch per step):
+ *   F = F(x);  the power / norm test of Bitzek et al. 2006 uses the sums L = (v.F, F.F, v.v) of
+ *   the PREVIOUS step (a one-step lag: a global sum of this step's F is only available to the
+ *   next launch), then the usual mixing, adaptive dt / alpha, semi-implicit Euler move with a
+ *   per-bead displacement clamp.  L is replaced by this step's sums.  A stage starts with
+ *   v = 0, L = 0, state (dt_start, alpha_start, 0). */
 void c3o_fire_step(const c3o_model* m, const int32_t* tgt10, const c3o_stage* st, const c3o_fire_params* fp,
-                   c3o_fire_state* fs, double* x, double* v, double* F) {
+                   c3o_fire_state* fs, double* L, double* x, double* v, double* F) {
     const int n = m->n;
+    c3o_energy_force(m, tgt10, x, st->w_all, st->w_vdw, st->repel_s, F, NULL);
     double vf = 0, ff = 0, vv = 0;
     for (int k = 0; k < 3 * n; ++k) { vf += v[k] * F[k]; ff += F[k] * F[k]; vv += v[k] * v[k]; }
-    if (vf > 0) {
-        const double mix = fs->alpha * sqrt(vv / (ff > 1e-300 ? ff : 1e-300));
+    if (L[0] > 0) {
+        const double mix = fs->alpha * sqrt(L[2] / (L[1] > 1e-30 ? L[1] : 1e-30));
         for (int k = 0; k < 3 * n; ++k) v[k] = (1.0 - fs->alpha) * v[k] + mix * F[k];
         if (fs->npos > fp->n_min) {
             fs->dt = fs->dt * fp->f_inc < fp->dt_max ? fs->dt * fp->f_inc : fp->dt_max;
@@ -454,7 +458,7 @@ void c3o_fire_step(const c3o_model* m, const int32_t* tgt10, const c3o_stage* st
         const double sc = d2 > fp->max_step * fp->max_step ? fp->max_step / sqrt(d2) : 1.0;
         for (int c = 0; c < 3; ++c) x[3 * i + c] += sc * dr[c];
     }
-    c3o_energy_force(m, tgt10, x, st->w_all, st->w_vdw, st->repel_s, F, NULL);
+    L[0] = vf; L[1] = ff; L[2] = vv;
 }
 
 /* Run a schedule of stages on one replica.  x (n*3) in/out, v scratch (n*3).
@@ -472,17 +476,12 @@ long c3o_run_schedule(const c3o_model* m, const int32_t* tgt10, const c3o_stage*
         const c3o_stage* st = &stages[s];
         if (st->kind == 2) {
             c3o_fire_state fs = {fp->dt_start, fp->alpha_start, 0, 1};
+            double L[3] = {0, 0, 0};
             for (int k = 0; k < 3 * n; ++k) v[k] = 0;
-            c3o_energy_force(m, tgt10, x, st->w_all, st->w_vdw, st->repel_s, F, NULL);
-            ++evals;
             for (int it = 0; it < st->nsteps; ++it) {
-                c3o_fire_step(m, tgt10, st, fp, &fs, x, v, F);
+                c3o_fire_step(m, tgt10, st, fp, &fs, L, x, v, F);
                 ++evals;
-                if (gtol > 0 && check_every > 0 && (it + 1) % check_every == 0) {
-                    double ff = 0;
-                    for (int k = 0; k < 3 * n; ++k) ff += F[k] * F[k];
-                    if (sqrt(ff / (3.0 * n)) < gtol) break;
-                }
+                if (gtol > 0 && check_every > 0 && (it + 1) % check_every == 0 && sqrt(L[1] / (3.0 * n)) < gtol) break;
             }
         } else {
             if (prev_kind == 2 || prev_kind == -1) c3o_init_velocities(m, seed, replica, 0.5, v);

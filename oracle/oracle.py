@@ -72,7 +72,7 @@ def lib():
         L.c3o_init_coords.argtypes = [C.POINTER(Model), C.c_uint64, C.c_uint32, dp]
         L.c3o_init_velocities.argtypes = [C.POINTER(Model), C.c_uint64, C.c_uint32, C.c_double, dp]
         L.c3o_md_step.argtypes = [C.POINTER(Model), i32p, C.POINTER(Stage), dp, dp, dp]
-        L.c3o_fire_step.argtypes = [C.POINTER(Model), i32p, C.POINTER(Stage), C.POINTER(FireParams), C.POINTER(FireState), dp, dp, dp]
+        L.c3o_fire_step.argtypes = [C.POINTER(Model), i32p, C.POINTER(Stage), C.POINTER(FireParams), C.POINTER(FireState), dp, dp, dp, dp]
         L.c3o_run_schedule.argtypes = [C.POINTER(Model), i32p, C.POINTER(Stage), C.c_int, C.POINTER(FireParams),
                                        C.c_double, C.c_int, C.c_uint64, C.c_uint32, dp, dp]
         L.c3o_run_schedule.restype = C.c_long

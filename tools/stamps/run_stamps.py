@@ -14,9 +14,9 @@ for cid in ("chr21_1mb", "chr1_500kb"):
     IF = load_if(cid)
     s.set_model(default_model()); pipeline.IF2dist_new(s, IF)
     for kind, st in (("md", [(1, 400, 0.005, 1.0, 0.01, 1.0, 300.0)]), ("fire", [(2, 400, 0.0, 1.0, 1.0, 0.85, 0.0)])):
-        for rpw in (2, 4):
+        for rpw in (2,):
             for nrep in (1, 20):
-                s.set_schedule(make_stages(st)); s.set_option("rows_per_wave", rpw); s.set_option("use_graph", 0)
+                s.set_schedule(make_stages(st)); s.set_option("rows_per_wave", rpw); s.set_option("use_graph", 0); s.set_option("replica_groups", 1)
                 s.init_replicas(nrep, 1, 0)
                 acc = []
                 s.run_steps(50)
