@@ -197,12 +197,15 @@ def main():
             "wall_s_per_chromosome_20_replicas": round(L * wall / args.steps, 4),
             "device_ms_timed_region": round(dev_ms_max, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "c3d::k_step<1,false>", "avg_launch_us": round(avg_launch_us, 3),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": 3.9e6 * M / 20 if n == 455 else None,
+                         "traffic_source": "profiles/r01_pmc_hbm_traffic_k_step.txt (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+                         "kernel": "c3d::k_step<1,false,2>", "avg_launch_us": round(avg_launch_us, 3),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "B = 4R + 72N per replica-step (SURVEY 8d) x replicas per launch; duration = HIP-event "
-                                 "time of the timed region / launches (includes inter-kernel gaps); the 0.8 MB target "
-                                 "matrix is L2-resident, so HBM traffic is far below B by design"},
+                         "note": "B = 4R + 72N per replica-step (SURVEY 8d) x replicas per SA step; duration = HIP-event time of "
+                                 "the timed region / SA steps (one step = one k_step launch per replica group, the groups "
+                                 "overlap on two streams); the 0.93 MB target matrix is shared by the replicas and stays in "
+                                 "L2, so fabric traffic is below B by design"},
         }
         out.update(extra)
         if not args.no_cpu_baseline:

@@ -70,3 +70,30 @@ def random_coil(n, seed, step=3.8):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     x = np.cumsum(step * d, axis=0)
     return (x - x.mean(0)).astype(np.float32)
+
+
+def synthetic_if(n, seed=20161015, K=11.0, alpha=0.5, sigma=0.2, radius=None):
+    """Config-5 style synthetic Hi-C matrix: ground truth = confined random walk with
+    3.8 A steps; IF_ij = (K / d_ij)^(1/alpha) * lognormal noise, symmetric, diagonal = 10 x row max.
+    Returns (IF, xyz_truth)."""
+    rng = np.random.default_rng(seed)
+    radius = radius if radius is not None else 2.2 * n ** (1.0 / 3.0) * 2.0
+    x = np.zeros((n, 3))
+    for i in range(1, n):
+        for _ in range(100):
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            cand = x[i - 1] + 3.8 * d
+            if np.linalg.norm(cand) <= radius:
+                break
+        x[i] = cand
+    d = np.linalg.norm(x[:, None, :] - x[None, :, :], axis=-1)
+    np.fill_diagonal(d, 1.0)
+    IF = (K / d) ** (1.0 / alpha)
+    g = rng.normal(size=(n, n))
+    g = (g + g.T) / np.sqrt(2.0)
+    IF = IF * np.exp(sigma * g)
+    IF = (IF + IF.T) / 2.0
+    np.fill_diagonal(IF, 0.0)
+    np.fill_diagonal(IF, 10.0 * IF.max(axis=1))
+    return IF, x - x.mean(0)
