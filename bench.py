@@ -159,7 +159,7 @@ def main():
     if finished is not None:
         xyz, en, b = finished
         xyz = xyz - xyz.mean(axis=1, keepdims=True)
-        rho = np.array([pipeline.spearman_IF_pdb(IF, xyz[r]) for r in range(M)])
+        rho = pipeline.spearman_IF_models(IF, xyz)
         ids = (b * world + rank) * M + np.arange(M)
         rec = sharding.pack_records(ids, en[:, 0], rho, xyz)
         tg = time.perf_counter()

@@ -230,25 +230,35 @@ extern "C" int c3d_read_pdb_ca(const char* path, float** xyz, int* n_out) {
     return C3D_OK;
 }
 
-static double round_dec(double d, int digits) {  // sprintf "%.Nf" then numeric use
-    char b[64];
-    snprintf(b, sizeof b, "%.*f", digits, d);
-    return strtod(b, nullptr);
+// Value of sprintf("%.3f", d) read back as a number, without going through text: the exact
+// product d*1000 is rounded to the nearest integer, ties to even (what glibc's printf does in
+// the default rounding mode); the fma residual settles the cases where fl(d*1000) sits on a tie.
+static inline long long round_milli(double d) {
+    const double p = d * 1000.0;
+    const double err = std::fma(d, 1000.0, -p);
+    double r = std::nearbyint(p);
+    const double diff = p - r;
+    if (diff == 0.5 || diff == -0.5) {
+        if (err > 0) r = std::floor(p) + 1.0;
+        else if (err < 0) r = std::floor(p);
+    }
+    return (long long)r;
 }
+static inline double round_dec3(double d) { return (double)round_milli(d) / 1000.0; }
 
 extern "C" int c3d_assess(const float* xyz, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10,
                           double relax, int* satisfied, double* sum_dev) {
     if (!xyz || (R > 0 && (!ri || !rj || !rt10))) return fail(C3D_ERR_INVALID, "c3d_assess: null argument");
     // the Perl reads coordinates back from the %8.3f PDB text
     std::vector<double> x((size_t)3 * n);
-    for (size_t k = 0; k < x.size(); ++k) x[k] = round_dec((double)xyz[k], 3);
+    for (size_t k = 0; k < x.size(); ++k) x[k] = round_dec3((double)xyz[k]);
     int count = 0;
     double sdev = 0;
     for (int k = 0; k < R; ++k) {
         const int i = ri[k] - 1, j = rj[k] - 1;
         if (i < 0 || j < 0 || i >= n || j >= n) return fail(C3D_ERR_INVALID, "c3d_assess: restraint index out of range");
         const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
-        const double d = round_dec(sqrt(dx * dx + dy * dy + dz * dz), 3);
+        const double d = round_dec3(sqrt(dx * dx + dy * dy + dz * dz));
         const double t = rt10[k] / 10.0;
         if (d < t + 0.0 + relax) ++count;
         if (d < t - 0.0 - relax) --count;
@@ -276,32 +286,59 @@ static void avg_ranks(const std::vector<double>& v, std::vector<double>& r) {
     }
 }
 
-extern "C" int c3d_spearman_if_dist(const double* IF, const float* xyz, int n, int range, double* rho) {
-    if (!IF || !xyz || !rho || n < 2) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist: bad arguments");
-    std::vector<double> x((size_t)3 * n);
-    for (size_t k = 0; k < x.size(); ++k) x[k] = round_dec((double)xyz[k], 3);
-    std::vector<double> a, b;
+// Spearman for M models of one matrix: the IF ranks are computed once; distances are integers in
+// thousandths of an Angstrom (the "%.3f" rounding of spearman_IF_pdb.pl:47), so their average
+// ranks come from a counting pass instead of a sort.
+extern "C" int c3d_spearman_if_dist_batch(const double* IF, const float* xyz, int n, int n_models, int range, double* rho) {
+    if (!IF || !xyz || !rho || n < 2 || n_models < 1) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist_batch: bad arguments");
+    std::vector<uint32_t> pi, pj;
+    std::vector<double> a;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             if (std::abs(i - j) < range) continue;
-            const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+            pi.push_back((uint32_t)i); pj.push_back((uint32_t)j);
             a.push_back(IF[(size_t)i * n + j]);
-            b.push_back(round_dec(sqrt(dx * dx + dy * dy + dz * dz), 3));
         }
-    if (a.size() < 2) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist: range leaves no pairs");
-    std::vector<double> ra, rb;
-    avg_ranks(a, ra);
-    avg_ranks(b, rb);
-    double ma = 0, mb = 0;
     const size_t m = a.size();
-    for (size_t k = 0; k < m; ++k) { ma += ra[k]; mb += rb[k]; }
-    ma /= m; mb /= m;
-    double sab = 0, saa = 0, sbb = 0;
-    for (size_t k = 0; k < m; ++k) {
-        sab += (ra[k] - ma) * (rb[k] - mb);
-        saa += (ra[k] - ma) * (ra[k] - ma);
-        sbb += (rb[k] - mb) * (rb[k] - mb);
+    if (m < 2) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist_batch: range leaves no pairs");
+    std::vector<double> ra;
+    avg_ranks(a, ra);
+    double ma = 0;
+    for (size_t k = 0; k < m; ++k) ma += ra[k];
+    ma /= m;
+    double saa = 0;
+    for (size_t k = 0; k < m; ++k) saa += (ra[k] - ma) * (ra[k] - ma);
+    std::vector<double> x((size_t)3 * n), rb(m);
+    std::vector<long long> dq(m);
+    for (int mdl = 0; mdl < n_models; ++mdl) {
+        const float* xm = xyz + (size_t)mdl * n * 3;
+        for (size_t k = 0; k < x.size(); ++k) x[k] = round_dec3((double)xm[k]);
+        long long dmax = 0;
+        for (size_t k = 0; k < m; ++k) {
+            const size_t i = pi[k], j = pj[k];
+            const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+            dq[k] = round_milli(sqrt(dx * dx + dy * dy + dz * dz));
+            if (dq[k] > dmax) dmax = dq[k];
+        }
+        if (dmax > 50000000LL) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist_batch: coordinates out of range");
+        std::vector<uint32_t> cnt((size_t)dmax + 2, 0);
+        for (size_t k = 0; k < m; ++k) ++cnt[(size_t)dq[k]];
+        std::vector<double> rank_of((size_t)dmax + 1);
+        size_t below = 0;
+        for (size_t v = 0; v <= (size_t)dmax; ++v) {
+            if (cnt[v]) rank_of[v] = 0.5 * ((double)below + (double)(below + cnt[v] - 1)) + 1.0;
+            below += cnt[v];
+        }
+        double mb = 0;
+        for (size_t k = 0; k < m; ++k) { rb[k] = rank_of[(size_t)dq[k]]; mb += rb[k]; }
+        mb /= m;
+        double sab = 0, sbb = 0;
+        for (size_t k = 0; k < m; ++k) { sab += (ra[k] - ma) * (rb[k] - mb); sbb += (rb[k] - mb) * (rb[k] - mb); }
+        rho[mdl] = sab / sqrt(saa * sbb);
     }
-    *rho = sab / sqrt(saa * sbb);
     return C3D_OK;
+}
+
+extern "C" int c3d_spearman_if_dist(const double* IF, const float* xyz, int n, int range, double* rho) {
+    return c3d_spearman_if_dist_batch(IF, xyz, n, 1, range, rho);
 }

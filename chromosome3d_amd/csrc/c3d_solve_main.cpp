@@ -10,6 +10,7 @@
 // iam.running is renamed iam.failed and the exit code is non-zero (:266-283).
 #include <sys/stat.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,7 +44,10 @@ static int fail_exit(const std::string& out_dir) {
     return 1;
 }
 
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int main(int argc, char** argv) {
+    const double t_start = now_s();
     std::string if_path, tbl_path, out_dir, id;
     double K = 11, alpha = 0.5, gtol = 1e-2;
     int models = 20, device = 0, n_beads = 0, min_steps = 3000, use_graph = 1, quiet = 0;
@@ -85,6 +89,7 @@ int main(int argc, char** argv) {
 
     c3d_ctx* ctx = nullptr;
     CHECK(c3d_create(device, &ctx));
+    const double t_ctx = now_s();
     c3d_model model;
     c3d_default_model(&model);
     CHECK(c3d_set_model(ctx, &model));
@@ -110,6 +115,7 @@ int main(int argc, char** argv) {
         CHECK(c3d_set_restraints(ctx, n, R, ri.data(), rj.data(), rt.data()));
     }
 
+    const double t_front = now_s();
     std::vector<c3d_stage> stages(c3d_default_schedule(nullptr, 0, min_steps));
     c3d_default_schedule(stages.data(), (int)stages.size(), min_steps);
     c3d_fire_params fire;
@@ -118,6 +124,7 @@ int main(int argc, char** argv) {
     CHECK(c3d_set_option(ctx, "use_graph", use_graph));
     CHECK(c3d_init_replicas(ctx, models, seed, first_rep));
     CHECK(c3d_run(ctx));
+    const double t_run = now_s();
 
     std::vector<float> xyz((size_t)models * n * 3);
     std::vector<double> en((size_t)models * 3);
@@ -137,13 +144,16 @@ int main(int argc, char** argv) {
         printf("c3d_solve: %d beads, %d restraints, %d models, %ld SA steps/model in %.1f ms on device %d (%.3g replica-steps/s)\n",
                n, R, models, steps, ms, device, ms > 0 ? 1e3 * (double)steps * models / ms : 0.0);
         if (IF) {
-            for (int r = 0; r < models; ++r) {
-                double rho = 0;
-                if (c3d_spearman_if_dist(IF, xyz.data() + (size_t)r * n * 3, n, 3, &rho) == C3D_OK)
-                    printf("  model %2u  E_noe %14.2f  Spearman(IF,d) %.4f\n", first_rep + r + 1, en[3 * r], rho);
-            }
+            std::vector<double> rho(models);
+            if (c3d_spearman_if_dist_batch(IF, xyz.data(), n, models, 3, rho.data()) == C3D_OK)
+                for (int r = 0; r < models; ++r)
+                    printf("  model %2u  E_noe %14.2f  Spearman(IF,d) %.4f\n", first_rep + r + 1, en[3 * r], rho[r]);
         }
     }
+    if (!quiet)
+        printf("c3d_solve wall: device init %.3f s, parse + K1 + front-half files %.3f s, anneal (incl. graph build) %.3f s, "
+               "read-back + PDB + scoring %.3f s, total %.3f s\n", t_ctx - t_start, t_front - t_ctx, t_run - t_front, now_s() - t_run,
+               now_s() - t_start);
     if (IF) c3d_free(IF);
     c3d_destroy(ctx);
     remove((out_dir + "/iam.running").c_str());

@@ -115,6 +115,15 @@ def spearman_IF_pdb(IF, xyz, rng=3):
     return rho.value
 
 
+def spearman_IF_models(IF, xyz, rng=3):
+    """spearman_IF_pdb for a stack of models [M, N, 3] of one matrix (IF ranked once)."""
+    IF = np.ascontiguousarray(IF, dtype=np.float64)
+    x = _l.as_f32(xyz)
+    rho = np.empty(x.shape[0], dtype=np.float64)
+    _l.check(_l.load().c3d_spearman_if_dist_batch(_l.dptr(IF), _l.fptr(x), IF.shape[0], x.shape[0], rng, _l.dptr(rho)))
+    return rho
+
+
 def build_models(solver, model_count=MODELCOUNT, seed=MD_SEED, first_replica=0, model=None, stages=None, fire=None,
                  gtol=1e-2, check_every=250):
     """The replacement of `cns_solve < dgsa.inp` (:254-289): runs the whole annealing schedule
@@ -163,7 +172,7 @@ def reconstruct(matrix_path, out_dir, K=KSCALING, alpha=ALPHA, model_count=MODEL
         xyz, en = build_models(s, model_count, **kw)
         rows = restraints_from_dist10(d10)
         order, _ = assess_dgsa(out_dir, ID, xyz, en, rows)
-        rho = [spearman_IF_pdb(IF, xyz[r]) for r in range(xyz.shape[0])]
+        rho = list(spearman_IF_models(IF, xyz))
         return dict(ID=ID, n=IF.shape[0], restraints=nres, order=order, spearman=rho, energies=en, xyz=xyz)
     finally:
         s.close()

@@ -156,6 +156,8 @@ int c3d_assess(const float* xyz, int n, int R, const int32_t* ri, const int32_t*
                double relax, int* satisfied, double* sum_dev);
 /* spearman_IF_pdb.pl:42-70 */
 int c3d_spearman_if_dist(const double* IF, const float* xyz, int n, int range, double* rho);
+/* the same for n_models models (n_models*n*3 coordinates) of one matrix: IF is ranked once */
+int c3d_spearman_if_dist_batch(const double* IF, const float* xyz, int n, int n_models, int range, double* rho);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,7 @@ for cid in cids:
     s.run()
     ms = s.last_timing()[0]
     x, e = s.coords(), s.energies()
-    rho = np.array([-pipeline.spearman_IF_pdb(IF, x[r]) for r in range(nrep)])
+    rho = -pipeline.spearman_IF_models(IF, x)
     order = np.argsort(e[:, 0].astype(np.int64), kind="stable")
     best = order[0]
     b = np.linalg.norm(x[best, 1:] - x[best, :-1], axis=1)
