@@ -84,8 +84,15 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # C3D_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+        backend = os.environ.get("C3D_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from chromosome3d_amd import Solver, default_fire, default_model, default_schedule, pipeline, sharding
     from tests.util import load_if
@@ -146,7 +153,7 @@ def main():
     sync_all()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms_max = float(t[0]), float(t[1])
     else:
@@ -163,7 +170,7 @@ def main():
         ids = (b * world + rank) * M + np.arange(M)
         rec = sharding.pack_records(ids, en[:, 0], rho, xyz)
         tg = time.perf_counter()
-        allrec = sharding.gather_records(rec, device="cuda" if dist is not None else None)
+        allrec = sharding.gather_records(rec, device="cuda" if dist is not None and dist.get_backend() == "nccl" else None)
         extra["gather_ms"] = round(1e3 * (time.perf_counter() - tg), 3)
         order = sharding.rank_models(allrec)
         extra["models_ranked"] = len(order)

@@ -32,6 +32,13 @@ namespace {
             return fail(C3D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
     } while (0)
 
+// frees a temporary device allocation on every exit path
+template <class T>
+struct DevTmp {
+    T* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+};
+
 struct Op {
     c3d::DevStep p;
     int stage;
@@ -326,9 +333,20 @@ int max_rms_force(c3d_ctx* c, double* out) {
     for (int r = 0; r < c->nrep; ++r) {
         double ff = 0;
         for (int t = 0; t < nparts; ++t) ff += h[((size_t)r * nparts + t) * 4 + 1];
-        worst = std::max(worst, sqrt(ff / (3.0 * c->n)));
+        const double rms = sqrt(ff / (3.0 * c->n));
+        if (!(rms <= worst)) worst = rms;   // NaN propagates
     }
     *out = worst;
+    return C3D_OK;
+}
+
+// are the last step's per-tile sums (functions of every velocity / force component) all finite?
+int partials_finite(c3d_ctx* c, bool* ok) {
+    std::vector<float> h((size_t)c->nrep * c->ntiles * 4);
+    HIP_TRY(hipMemcpyAsync(h.data(), c->buf.P[c->parity], sizeof(float) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *ok = true;
+    for (float v : h) if (!std::isfinite(v)) { *ok = false; break; }
     return C3D_OK;
 }
 
@@ -483,29 +501,33 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
     return fail(C3D_ERR_INVALID, std::string("unknown option ") + key);
 }
 
+// 3*npad floats of LDS per workgroup must stay below the 64 KB a launch gets without opt-in
+static constexpr int kMaxBeads = 5120;
+
 extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alpha, double K) {
     if (!c || !IF || n < 2) return fail(C3D_ERR_INVALID, "c3d_set_if_matrix: bad arguments");
+    if (n > kMaxBeads) return fail(C3D_ERR_INVALID, "c3d_set_if_matrix: more than 5120 beads are not supported by this build");
     HIP_TRY(hipSetDevice(c->device));
     free_replica_buffers(c);
     set_dims(c, n);
     const size_t nn = (size_t)n * n;
-    double *dIF = nullptr, *dP = nullptr, *dpart = nullptr;
-    int32_t* ddist = nullptr;
+    DevTmp<double> dIF, dP, dpart;
+    DevTmp<int32_t> ddist;
     const int npartial = 64;
     if (c->buf.tgt) { hipFree(c->buf.tgt); c->buf.tgt = nullptr; }
-    HIP_TRY(hipMalloc(&dIF, sizeof(double) * nn));
-    HIP_TRY(hipMalloc(&dP, sizeof(double) * nn));
-    HIP_TRY(hipMalloc(&dpart, sizeof(double) * npartial));
-    HIP_TRY(hipMalloc(&ddist, sizeof(int32_t) * nn));
+    c->have_targets = false;
+    HIP_TRY(hipMalloc(&dIF.p, sizeof(double) * nn));
+    HIP_TRY(hipMalloc(&dP.p, sizeof(double) * nn));
+    HIP_TRY(hipMalloc(&dpart.p, sizeof(double) * npartial));
+    HIP_TRY(hipMalloc(&ddist.p, sizeof(int32_t) * nn));
     HIP_TRY(hipMalloc(&c->buf.tgt, sizeof(float) * (size_t)n * c->npad));
-    HIP_TRY(hipMemcpyAsync(dIF, IF, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
-    hipError_t e = c3d::launch_if_to_target(dIF, n, c->npad, alpha, K, c->model.min_sep, c->model.rep_sep, dP, dpart,
-                                            npartial, ddist, c->buf.tgt, c->stream);
+    HIP_TRY(hipMemcpyAsync(dIF.p, IF, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
+    hipError_t e = c3d::launch_if_to_target(dIF.p, n, c->npad, alpha, K, c->model.min_sep, c->model.rep_sep, dP.p, dpart.p,
+                                            npartial, ddist.p, c->buf.tgt, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("K1 launch: ") + hipGetErrorString(e));
     c->h_dist10.resize(nn);
-    HIP_TRY(hipMemcpyAsync(c->h_dist10.data(), ddist, sizeof(int32_t) * nn, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_dist10.data(), ddist.p, sizeof(int32_t) * nn, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    hipFree(dIF); hipFree(dP); hipFree(dpart); hipFree(ddist);
     int R = 0;
     for (int i = 0; i < n; ++i)
         for (int j = i + 1; j < n; ++j)
@@ -518,6 +540,7 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
 
 extern "C" int c3d_set_restraints(c3d_ctx* c, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10) {
     if (!c || n < 2 || R < 0 || (R > 0 && (!ri || !rj || !rt10))) return fail(C3D_ERR_INVALID, "c3d_set_restraints: bad arguments");
+    if (n > kMaxBeads) return fail(C3D_ERR_INVALID, "c3d_set_restraints: more than 5120 beads are not supported by this build");
     HIP_TRY(hipSetDevice(c->device));
     free_replica_buffers(c);
     set_dims(c, n);
@@ -719,7 +742,14 @@ extern "C" int c3d_run(c3d_ctx* c) {
     }
     hipError_t e = c3d::launch_centre(dev_model(c), c->buf, c->parity, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("centre launch: ") + hipGetErrorString(e));
-    return end_timing(c);
+    rc = end_timing(c);
+    if (rc) return rc;
+    // a blown-up trajectory (NaN/Inf) must not reach the caller as a "model"
+    bool finite = true;
+    rc = partials_finite(c, &finite);
+    if (rc) return rc;
+    if (!finite) return fail(C3D_ERR_DIVERGED, "c3d_run: the trajectory diverged (non-finite forces); reduce the time step or stiffness");
+    return C3D_OK;
 }
 
 extern "C" int c3d_last_timing(const c3d_ctx* c, double* ms_total, long* steps, long* launches) {

@@ -33,7 +33,8 @@ typedef enum {
     C3D_ERR_NO_DEVICE = -2,  /* no HIP device, or the gfx950 code object cannot load */
     C3D_ERR_HIP = -3,        /* a HIP runtime call failed */
     C3D_ERR_IO = -4,         /* file could not be read / written / parsed */
-    C3D_ERR_NOMEM = -5
+    C3D_ERR_NOMEM = -5,
+    C3D_ERR_DIVERGED = -6    /* non-finite coordinates/forces after a run */
 } c3d_status;
 
 typedef struct c3d_ctx c3d_ctx;

@@ -286,3 +286,30 @@ def test_full_schedule_statistics(solver, O, cid, tol_ref):
     assert abs(rho[best] - REF_SPEARMAN[cid]) < tol_ref, (rho[best], REF_SPEARMAN[cid])
     order = s.rank()
     assert order[0] == best or int(en[order[0], 0]) == int(en[best, 0])
+
+
+def test_divergence_is_reported_not_returned(solver):
+    """An unstable time step must come back as an error, never as a 'model'."""
+    from chromosome3d_amd import C3DError
+    _setup(solver, "chr21_1mb", [(0, 200, 0.5, 1.0, 1.0, 0.9, 2000.0)], nrep=3)
+    with pytest.raises(C3DError, match="diverged"):
+        solver.run()
+    # the context stays usable
+    _setup(solver, "chr21_1mb", [(0, 50, 0.003, 1.0, 1.0, 0.9, 2000.0)], nrep=3)
+    solver.run()
+    assert np.isfinite(solver.coords()).all()
+
+
+def test_replica_groups_do_not_change_results(solver):
+    """Stepping the replicas as 1, 2 or 3 stream groups is a scheduling choice: bitwise same models."""
+    stages = [(2, 30, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 60, 0.003, 0.4, 0.003, 0.9, 2000.0), (1, 36, 0.005, 1.0, 0.1, 0.95, 1000.0),
+              (2, 80, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    out = []
+    for g in (1, 2, 3):
+        _setup(solver, "chr20_1mb", stages, nrep=7)
+        solver.set_option("replica_groups", g)
+        solver.run()
+        out.append((solver.coords(), solver.energies()))
+    solver.set_option("replica_groups", 2)
+    for k in (1, 2):
+        assert np.array_equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1])
