@@ -100,3 +100,20 @@ def test_perl_driver_same_cli_and_outputs(built, tmp_path):
     # bad usage -> non-zero exit like the reference's print_usage / confess
     assert subprocess.run(["perl", drv, "-o", str(tmp_path / "x")], capture_output=True).returncode != 0
     assert subprocess.run(["perl", drv, "-i", "/nonexistent.txt", "-o", str(tmp_path / "x")], capture_output=True).returncode != 0
+
+
+@pytest.mark.gpu
+def test_batch_script_runs_every_matrix(built, tmp_path):
+    """test.sh twin: one job per *_matrix.txt, logs + ranked models per chromosome."""
+    if shutil.which("perl") is None:
+        pytest.skip("no perl on this box")
+    ind = tmp_path / "in"
+    ind.mkdir()
+    for cid in ("chr21_1mb", "chr22_1mb"):
+        shutil.copy(os.path.join(GOLD, "inputs", f"{cid}_matrix.txt"), ind)
+    out = subprocess.run(["bash", os.path.join(ROOT, "bin", "run_all_amd.sh"), str(ind), str(tmp_path / "out"), "1", "-m", "6"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "FAILED" not in out.stdout, out.stdout + out.stderr
+    for cid in ("chr21_1mb", "chr22_1mb"):
+        assert (tmp_path / "out" / f"{cid}.log").exists()
+        assert len(list((tmp_path / "out" / cid).glob(f"{cid}_matrix_model*.pdb"))) == 5
