@@ -645,6 +645,37 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
     return C3D_OK;
 }
 
+// A7: replace the replicas' starting coordinates by a metric-matrix distance-geometry embedding
+// (deck :1471-1525 restated for beads; one embed per model, trial distances keyed by replica id)
+extern "C" int c3d_embed_replicas(c3d_ctx* c, int iters) {
+    if (!c || iters < 1) return fail(C3D_ERR_INVALID, "c3d_embed_replicas: bad arguments");
+    if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_embed_replicas: call c3d_init_replicas first");
+    if ((size_t)9 * c->n + 16 > 160 * 1024 / sizeof(float)) return fail(C3D_ERR_INVALID, "c3d_embed_replicas: too many beads for the embedding kernel");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = c->n, nrep = c->nrep;
+    const size_t nn = (size_t)n * n;
+    DevTmp<float> U, L, D2, v0;
+    HIP_TRY(hipMalloc(&U.p, sizeof(float) * nn));
+    HIP_TRY(hipMalloc(&L.p, sizeof(float) * nn));
+    HIP_TRY(hipMalloc(&D2.p, sizeof(float) * nn * nrep));
+    HIP_TRY(hipMalloc(&v0.p, sizeof(float) * 3 * n * nrep));
+    std::vector<float> hv((size_t)3 * n * nrep);
+    for (int r = 0; r < nrep; ++r)
+        for (int i = 0; i < n; ++i) {
+            double g[4];
+            normals4(c->seed, c->first_rep + (uint32_t)r, (uint32_t)i, 3u, g);
+            for (int k = 0; k < 3; ++k) hv[((size_t)r * 3 + k) * n + i] = (float)g[k];
+        }
+    HIP_TRY(hipMemcpyAsync(v0.p, hv.data(), sizeof(float) * hv.size(), hipMemcpyHostToDevice, c->stream));
+    float repel_s = 0.85f;
+    if (!c->stages.empty()) repel_s = c->stages.back().repel_s;
+    hipError_t e = c3d::launch_dg_embed(c->buf.tgt, n, c->npad, nrep, c->model.b0, repel_s * c->model.r0_rep, c->seed, c->first_rep,
+                                        iters, v0.p, U.p, L.p, D2.p, c->buf.X[0], c->buf.X[1], c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("embed launch: ") + hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C3D_OK;
+}
+
 extern "C" int c3d_set_coords(c3d_ctx* c, const float* xyz) {
     if (!c || !xyz) return fail(C3D_ERR_INVALID, "c3d_set_coords: null argument");
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_set_coords: call c3d_init_replicas first");

@@ -82,6 +82,11 @@ hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, 
                                double* scratchP, double* partial, int npartial, int32_t* dist10, float* tgt,
                                hipStream_t s);
 
+// A7 (c3d_embed.hip): bead-level metric-matrix distance geometry for every replica
+hipError_t launch_dg_embed(const float* tgt, int n, int npad, int nrep, float b0, float lower, uint64_t seed,
+                           uint32_t first_replica, int iters, const float* v0, float* U, float* L, float* D2, float* x0,
+                           float* x1, hipStream_t s);
+
 // Target matrix entry: NOE target in Angstrom, 0 = no restraint (host c3d_set_restraints and K1).
 inline float encode_target_host(float t, bool) { return t > 0 ? t : 0.0f; }
 

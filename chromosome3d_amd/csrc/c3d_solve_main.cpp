@@ -23,7 +23,7 @@ static void usage() {
     fprintf(stderr,
             "usage: c3d_solve (--if <IF matrix> | --tbl <contact.tbl> --n <beads>) --out <dir> [--id <ID>]\n"
             "                 [-k <K=11>] [-a <alpha=0.5>] [-m <models=20>] [--seed <82364>] [--first-replica <0>]\n"
-            "                 [--device <0>] [--min-steps <3000>] [--gtol <1e-2>] [--no-graph] [--quiet]\n");
+            "                 [--device <0>] [--min-steps <3000>] [--gtol <1e-2>] [--embed] [--no-graph] [--quiet]\n");
 }
 
 #define CHECK(call)                                                              \
@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     const double t_start = now_s();
     std::string if_path, tbl_path, out_dir, id;
     double K = 11, alpha = 0.5, gtol = 1e-2;
-    int models = 20, device = 0, n_beads = 0, min_steps = 3000, use_graph = 1, quiet = 0;
+    int models = 20, device = 0, n_beads = 0, min_steps = 3000, use_graph = 1, quiet = 0, embed = 0;
     unsigned long long seed = 82364ULL;
     unsigned first_rep = 0;
     for (int a = 1; a < argc; ++a) {
@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
         else if (s == "--device") device = atoi(next("--device"));
         else if (s == "--min-steps") min_steps = atoi(next("--min-steps"));
         else if (s == "--gtol") gtol = atof(next("--gtol"));
+        else if (s == "--embed") embed = 1;   // distance-geometry start (deck :1471-1525) instead of the random coil
         else if (s == "--no-graph") use_graph = 0;
         else if (s == "--quiet") quiet = 1;
         else if (s == "-h" || s == "--help") { usage(); return 0; }
@@ -123,6 +124,7 @@ int main(int argc, char** argv) {
     CHECK(c3d_set_schedule(ctx, stages.data(), (int)stages.size(), &fire, (float)gtol, 250));
     CHECK(c3d_set_option(ctx, "use_graph", use_graph));
     CHECK(c3d_init_replicas(ctx, models, seed, first_rep));
+    if (embed) CHECK(c3d_embed_replicas(ctx, 50));
     CHECK(c3d_run(ctx));
     const double t_run = now_s();
 

@@ -96,6 +96,10 @@ class Solver:
         _l.check(self._L.c3d_init_replicas(self._h, nrep, seed, first_replica))
         self.nrep = nrep
 
+    def embed(self, iters=50):
+        """A7: metric-matrix distance-geometry start for every replica."""
+        _l.check(self._L.c3d_embed_replicas(self._h, iters))
+
     def set_coords(self, xyz):
         xyz = _l.as_f32(xyz)
         assert xyz.shape == (self.nrep, self.n, 3)

@@ -109,6 +109,11 @@ int c3d_set_option(c3d_ctx* ctx, const char* key, double value);
  * Philox4x32-10 keyed by (seed, replica id), so a replica's trajectory does not depend on
  * how replicas are spread over processes or GPUs (seed 82364: chromosome3D.pl:980). */
 int c3d_init_replicas(c3d_ctx* ctx, int n_replicas, uint64_t seed, uint32_t first_replica);
+/* A7 (deck chromosome3D.pl:1471-1525, bead-level restatement): replace the random-coil start of every
+ * replica by a metric-matrix distance-geometry embedding — bounds from the restraints, triangle
+ * smoothing, random trial distances (Philox, keyed by replica id), 3 leading eigenvectors found with
+ * `iters` orthogonal iterations (50 is plenty).  Call between c3d_init_replicas and c3d_run. */
+int c3d_embed_replicas(c3d_ctx* ctx, int iters);
 /* overwrite coordinates (n_replicas*n*3, xyz interleaved) — tests and restarts */
 int c3d_set_coords(c3d_ctx* ctx, const float* xyz);
 int c3d_get_coords(c3d_ctx* ctx, float* xyz);

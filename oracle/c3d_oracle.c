@@ -575,3 +575,123 @@ double c3o_spearman_if_dist(const double* IF, const double* x, int n, int range)
     free(a); free(b); free(ra); free(rb);
     return sab / sqrt(saa * sbb);
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* A7: metric-matrix distance geometry at bead level (deck :1471-1525, knobs :1008-1090)   */
+/*   bounds  -> triangle smoothing (shortest paths) -> random trial distances ->           */
+/*   metric (Gram) matrix -> top-3 eigenvectors (orthogonal iteration) -> coordinates.     */
+/* The reference embeds a substructure of the pseudo-protein with CNS `mmdg`; here every   */
+/* bead is embedded: bond pairs are fixed at b0, restrained pairs at their target          */
+/* (dminus = dplus = 0, chromosome3D.pl:352-354), the rest gets [lower_default, +inf).     */
+/* ------------------------------------------------------------------------------------ */
+#define C3O_DG_INF 1.0e30
+void c3o_dg_bounds(const c3o_model* m, const int32_t* tgt10, double lower_default, double* U, double* L) {
+    const int n = m->n;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int sep = abs(i - j);
+            double u = C3O_DG_INF, l = lower_default;
+            const int32_t t10 = tgt10[(size_t)i * n + j];
+            if (sep == 0) { u = 0; l = 0; }
+            else if (sep == 1) { u = m->b0; l = m->b0; }
+            else if (sep >= m->min_sep && t10 > 0) { u = 0.1 * t10; l = 0.1 * t10; }
+            U[(size_t)i * n + j] = u;
+            L[(size_t)i * n + j] = l;
+        }
+}
+/* upper bounds: all-pairs shortest paths (Floyd-Warshall); lower bounds: inverse triangle
+ * inequality with the smoothed upper bounds; finally L <= U is enforced */
+void c3o_dg_smooth(int n, double* U, double* L) {
+    for (int k = 0; k < n; ++k)
+        for (int i = 0; i < n; ++i) {
+            const double uik = U[(size_t)i * n + k];
+            for (int j = 0; j < n; ++j) {
+                const double v = uik + U[(size_t)k * n + j];
+                if (v < U[(size_t)i * n + j]) U[(size_t)i * n + j] = v;
+            }
+        }
+    for (int k = 0; k < n; ++k)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const double a = L[(size_t)i * n + k] - U[(size_t)k * n + j];
+                const double b = L[(size_t)k * n + j] - U[(size_t)i * n + k];
+                double v = L[(size_t)i * n + j];
+                if (a > v) v = a;
+                if (b > v) v = b;
+                L[(size_t)i * n + j] = v;
+            }
+    for (size_t q = 0; q < (size_t)n * n; ++q) if (L[q] > U[q]) L[q] = U[q];
+}
+/* trial distance of pair (i<j): uniform in [L, U], Philox counter (i, j, 2) */
+static double dg_uniform(uint64_t seed, uint32_t replica, uint32_t i, uint32_t j) {
+    uint32_t ctr[4] = {i, j, 2u, 0u};
+    uint32_t key[2] = {(uint32_t)(seed & 0xFFFFFFFFu) ^ (replica * 0x9E3779B9u), (uint32_t)(seed >> 32) + replica};
+    uint32_t r[4];
+    c3o_philox4x32(ctr, key, r);
+    return u01(r[0]);
+}
+void c3o_dg_trial_d2(int n, const double* U, const double* L, uint64_t seed, uint32_t replica, double* D2) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            if (i == j) { D2[(size_t)i * n + j] = 0; continue; }
+            const int a = i < j ? i : j, b = i < j ? j : i;
+            const double lo = L[(size_t)a * n + b], hi = U[(size_t)a * n + b];
+            const double d = lo + dg_uniform(seed, replica, (uint32_t)a, (uint32_t)b) * (hi - lo);
+            D2[(size_t)i * n + j] = d * d;
+        }
+}
+/* y = B v with B = -1/2 J D2 J (J = centring projector) */
+static void dg_matvec(int n, const double* D2, const double* v, double* y) {
+    double mv = 0;
+    for (int i = 0; i < n; ++i) mv += v[i];
+    mv /= n;
+    double mz = 0;
+    for (int i = 0; i < n; ++i) {
+        double z = 0;
+        for (int j = 0; j < n; ++j) z += D2[(size_t)i * n + j] * (v[j] - mv);
+        y[i] = z;
+        mz += z;
+    }
+    mz /= n;
+    for (int i = 0; i < n; ++i) y[i] = -0.5 * (y[i] - mz);
+}
+/* orthogonal (subspace) iteration for the 3 leading eigenpairs; x = sqrt(lambda_k) v_k, centred */
+void c3o_dg_embed(int n, const double* D2, uint64_t seed, uint32_t replica, int iters, double* x) {
+    double* V = (double*)malloc(sizeof(double) * 3 * (size_t)n);
+    double* W = (double*)malloc(sizeof(double) * 3 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        double g[4];
+        normals4(seed, replica, (uint32_t)i, 3u, g);
+        for (int k = 0; k < 3; ++k) V[(size_t)k * n + i] = g[k];
+    }
+    double lam[3] = {0, 0, 0};
+    for (int it = 0; it <= iters; ++it) {
+        for (int k = 0; k < 3; ++k) dg_matvec(n, D2, V + (size_t)k * n, W + (size_t)k * n);
+        if (it == iters) {   /* Rayleigh quotients with the current orthonormal V */
+            for (int k = 0; k < 3; ++k) {
+                double s = 0;
+                for (int i = 0; i < n; ++i) s += V[(size_t)k * n + i] * W[(size_t)k * n + i];
+                lam[k] = s;
+            }
+            break;
+        }
+        for (int k = 0; k < 3; ++k) {   /* modified Gram-Schmidt */
+            for (int q = 0; q < k; ++q) {
+                double s = 0;
+                for (int i = 0; i < n; ++i) s += W[(size_t)k * n + i] * V[(size_t)q * n + i];
+                for (int i = 0; i < n; ++i) W[(size_t)k * n + i] -= s * V[(size_t)q * n + i];
+            }
+            double nn = 0;
+            for (int i = 0; i < n; ++i) nn += W[(size_t)k * n + i] * W[(size_t)k * n + i];
+            nn = sqrt(nn > 1e-300 ? nn : 1e-300);
+            for (int i = 0; i < n; ++i) V[(size_t)k * n + i] = W[(size_t)k * n + i] / nn;
+        }
+    }
+    double c[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        const double s = sqrt(lam[k] > 0 ? lam[k] : 0);
+        for (int i = 0; i < n; ++i) { x[3 * i + k] = s * V[(size_t)k * n + i]; c[k] += x[3 * i + k]; }
+    }
+    for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) x[3 * i + k] -= c[k] / n;
+    free(V); free(W);
+}

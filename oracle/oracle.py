@@ -79,6 +79,12 @@ def lib():
         L.c3o_assess.argtypes = [dp, C.c_int, ip, ip, i32p, C.c_double, ip, dp]
         L.c3o_spearman_if_dist.argtypes = [dp, dp, C.c_int, C.c_int]
         L.c3o_spearman_if_dist.restype = C.c_double
+        L.c3o_dg_bounds.argtypes = [C.POINTER(Model), i32p, C.c_double, dp, dp]
+        L.c3o_dg_smooth.argtypes = [C.c_int, dp, dp]
+        L.c3o_dg_trial_d2.argtypes = [C.c_int, dp, dp, C.c_uint64, C.c_uint32, dp]
+        L.c3o_dg_embed.argtypes = [C.c_int, dp, C.c_uint64, C.c_uint32, C.c_int, dp]
+        for f in (L.c3o_dg_bounds, L.c3o_dg_smooth, L.c3o_dg_trial_d2, L.c3o_dg_embed):
+            f.restype = None
         L.c3o_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
@@ -202,3 +208,31 @@ def spearman_if_dist(IF, x, rng=3):
     IF = np.ascontiguousarray(IF, dtype=np.float64)
     x = np.ascontiguousarray(x, dtype=np.float64)
     return lib().c3o_spearman_if_dist(_dp(IF), _dp(x), IF.shape[0], rng)
+
+
+def dg_bounds(model, tgt10, lower_default):
+    n = model.n
+    U = np.empty((n, n)); Lo = np.empty((n, n))
+    t = np.ascontiguousarray(tgt10, dtype=np.int32)
+    lib().c3o_dg_bounds(C.byref(model), _i32p(t), lower_default, _dp(U), _dp(Lo))
+    return U, Lo
+
+
+def dg_smooth(U, Lo):
+    U = np.array(U, dtype=np.float64, order="C"); Lo = np.array(Lo, dtype=np.float64, order="C")
+    lib().c3o_dg_smooth(U.shape[0], _dp(U), _dp(Lo))
+    return U, Lo
+
+
+def dg_trial_d2(U, Lo, seed, replica):
+    n = U.shape[0]
+    D2 = np.empty((n, n))
+    lib().c3o_dg_trial_d2(n, _dp(np.ascontiguousarray(U)), _dp(np.ascontiguousarray(Lo)), seed, replica, _dp(D2))
+    return D2
+
+
+def dg_embed(D2, seed, replica, iters=50):
+    n = D2.shape[0]
+    x = np.zeros((n, 3))
+    lib().c3o_dg_embed(n, _dp(np.ascontiguousarray(D2)), seed, replica, iters, _dp(x))
+    return x

@@ -313,3 +313,32 @@ def test_replica_groups_do_not_change_results(solver):
     solver.set_option("replica_groups", 2)
     for k in (1, 2):
         assert np.array_equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1])
+
+
+@pytest.mark.parametrize("cid", ["chr21_1mb", "chr13_1mb"])
+def test_dg_embedding_matches_oracle(solver, O, cid):
+    """A7 (deck :1471-1525, bead level): bounds -> smoothing -> trial distances -> top-3 eigenvectors.
+    Eigenvector signs / rotations are gauge: compare the embedded pair distances."""
+    from chromosome3d_amd import default_model, pipeline
+    IF = load_if(cid)
+    n = IF.shape[0]
+    m = default_model()
+    solver.set_model(m)
+    d10 = pipeline.IF2dist_new(solver, IF)
+    solver.init_replicas(3, 82364, 4)
+    solver.embed(50)
+    x = solver.coords()
+    om = oracle_model_from(m, n)
+    U, L = O.dg_smooth(*O.dg_bounds(om, d10, float(np.float32(0.85) * m.r0_rep)))
+    iu = np.triu_indices(n, 1)
+    for r in range(3):
+        xo = O.dg_embed(O.dg_trial_d2(U, L, 82364, 4 + r), 82364, 4 + r, 50)
+        dg = np.linalg.norm(x[r][:, None] - x[r][None], axis=-1)[iu]
+        do = np.linalg.norm(xo[:, None] - xo[None], axis=-1)[iu]
+        assert np.abs(dg - do).max() < 2e-3 * do.max(), np.abs(dg - do).max()
+        assert abs(x[r].mean(0)).max() < 1e-3
+    # the embedded start is already correlated with the data and the schedule runs from it
+    rho0 = pipeline.spearman_IF_models(IF, x)
+    assert (rho0 < -0.5).all()
+    solver.run()
+    assert np.isfinite(solver.coords()).all()

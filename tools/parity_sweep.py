@@ -17,6 +17,7 @@ nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 subset = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
 min_steps = int(over.pop("min_steps", 3000))
 quiet = over.pop("quiet", 0)
+embed = over.pop("embed", 0)
 
 def load(cid):
     z = np.load(f"{ALL}/{cid}_upper.npz"); n = int(z["n"]); m = np.zeros((n, n)); iu = np.triu_indices(n)
@@ -38,6 +39,8 @@ for cid in cids:
     pipeline.IF2dist_new(s, IF)
     s.set_schedule(default_schedule(min_steps), default_fire(), 0.0, 250)
     s.init_replicas(nrep, 82364, 0)
+    if embed:
+        s.embed(50)
     s.run()
     ms = s.last_timing()[0]
     x, e = s.coords(), s.energies()
