@@ -9,8 +9,9 @@
 #   build_models: job.sh -> cns_solve < dgsa.inp     job.sh -> c3d_solve (C ABI of libc3d.so)
 #   assess_dgsa (:106, :769-829)                     same ranking / table / renaming, below
 #
-# The FFI is the C ABI in include/c3d.h; this script reaches it through the c3d_solve
-# executable (always available); INTEGRATION.md shows the XS binding for in-process calls.
+# The FFI is the C ABI in include/c3d.h.  In-process route: the XS module bindings/perl (C3D::solve calls
+# c3d_set_if_matrix / c3d_run / ... directly).  Fallback when the module is not built (or C3D_FORCE_CLI=1):
+# job.sh + the c3d_solve executable, i.e. the reference's own process boundary.
 use strict;
 use warnings;
 use Cwd 'abs_path';
@@ -29,8 +30,16 @@ usage("Input IF matrix not found!") if not defined $file_if;
 usage("Output directory not defined!") if not defined $dir_out;
 usage("Input IF file $file_if does not exist!") if not -f $file_if;
 
+my $have_xs = 0;
+if (not $ENV{C3D_FORCE_CLI}) {
+	my $blib = abs_path(dirname(abs_path($0))."/../bindings/perl/blib");
+	if (defined $blib and -f "$blib/C3D.pm") {
+		unshift @INC, $blib;
+		$have_xs = eval { require C3D; 1 } ? 1 : 0;
+	}
+}
 my $solver = $ENV{C3D_SOLVE} || abs_path(dirname(abs_path($0))."/../chromosome3d_amd/_lib/c3d_solve");
-die "ERROR! c3d_solve not found at $solver (build: python -c 'import __graft_entry__ as g; g.build()')\n" if not -x $solver;
+die "ERROR! neither the C3D XS module nor c3d_solve ($solver) is built (python -c 'import __graft_entry__ as g; g.build()')\n" if not $have_xs and not -x $solver;
 
 mkdir $dir_out or die "ERROR! Could not create output directory $dir_out!\n" if not -d $dir_out;
 print "Start Time : ".(localtime)." [$0]\n";
@@ -45,7 +54,25 @@ unlink map { "$dir_out/$_" } ("$ID.dist", "$ID.rr", "contact.tbl", "job.sh", "jo
 copy($file_if, "$dir_out/$ID.txt") or die "ERROR! cannot copy $file_if: $!\n" if abs_path($file_if) ne (abs_path("$dir_out/$ID.txt") || "");
 chdir $dir_out or die $!;
 
-# (B) build models — the process boundary of the reference, same sentinel protocol (:258-288)
+# (B) build models
+my $restraints;
+if ($have_xs) {
+	# in-process FFI: Perl -> XS -> C ABI -> HIP kernels
+	print "(B) Build models using libc3d (MI355X) through the C3D XS binding..\n";
+	system("touch iam.running");
+	my $r = eval { C3D::solve("$ID.txt", ".", $ID, $MODELS, $K, $ALPHA + 0, $SEED, $DEVICE, 0) };
+	if (not defined $r) {
+		rename "iam.running", "iam.failed";
+		die "ERROR! Something went wrong inside libc3d: $@";
+	}
+	unlink "iam.running";
+	$restraints = $r->{restraints};
+	open my $jl, ">", "job.log" or die $!;
+	printf $jl "C3D XS binding: %d beads, %d restraints, %d models, %d SA steps in %.1f ms on device %d\n", $r->{n}, $r->{restraints}, $MODELS, $r->{steps}, $r->{ms}, $DEVICE;
+	close $jl;
+}
+else {
+# the process boundary of the reference, same sentinel protocol (:258-288)
 open my $job, ">", "job.sh" or die $!;
 print $job "#!/bin/bash\necho \"starting c3d_solve..\"\ntouch iam.running\n";
 print $job "\"$solver\" --if \"$ID.txt\" --out . --id \"$ID\" -k $K -a $ALPHA -m $MODELS --seed $SEED --device $DEVICE\n";
@@ -56,7 +83,8 @@ chmod 0755, "job.sh";
 print "(B) Build models using libc3d (MI355X)..\nStarting job [$dir_out/job.sh > job.log]\n";
 system("./job.sh > job.log 2>&1");
 die "ERROR! Something went wrong while running c3d_solve! Check job.log!\n".`tail -n 5 job.log` if -f "iam.failed" or not -f "${ID}_${MODELS}.pdb";
-my ($restraints) = `cat job.log` =~ /Restraints : (\d+)/;
+($restraints) = `cat job.log` =~ /Restraints : (\d+)/;
+}
 print "L          : ".first_line_fields("$ID.txt")."\n";
 print "Restraints : ".($restraints // "?")." lines in tbl file\n";
 

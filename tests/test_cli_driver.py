@@ -68,12 +68,16 @@ def test_perl_driver_same_cli_and_outputs(built, tmp_path):
     if shutil.which("perl") is None:
         pytest.skip("no perl on this box")
     drv = os.path.join(ROOT, "bin", "chromosome3D_amd.pl")
-    for flag in ("-i", "-if"):
+    have_xs = os.path.exists(os.path.join(ROOT, "bindings", "perl", "blib", "auto", "C3D", "C3D.so"))
+    # -i through the in-process XS binding (when built), -if through the job.sh / c3d_solve process boundary
+    for flag, force_cli in (("-i", "0"), ("-if", "1")):
         od = tmp_path / f"out{flag}"
-        out = subprocess.run(["perl", drv, flag, MATRIX, "-o", str(od), "-m", "7"], capture_output=True, text=True)
+        env = dict(os.environ, C3D_FORCE_CLI=force_cli) if force_cli == "1" else {k: v for k, v in os.environ.items() if k != "C3D_FORCE_CLI"}
+        out = subprocess.run(["perl", drv, flag, MATRIX, "-o", str(od), "-m", "7"], capture_output=True, text=True, env=env)
         assert out.returncode == 0, out.stdout + out.stderr
+        assert ("through the C3D XS binding" in out.stdout) == (have_xs and force_cli == "0")
         cid = "chr21_1mb_matrix"
-        for f in (f"{cid}.txt", f"{cid}.dist", f"{cid}.rr", "contact.tbl", "job.sh", "job.log", "model_info.log"):
+        for f in (f"{cid}.txt", f"{cid}.dist", f"{cid}.rr", "contact.tbl", "job.log", "model_info.log"):
             assert (od / f).exists(), f
         assert open(od / "contact.tbl", "rb").read() == open(os.path.join(GOLD, "chr21_1mb.contact.tbl"), "rb").read()
         models = sorted(od.glob(f"{cid}_model*.pdb"))
