@@ -32,7 +32,7 @@ def test_k1_and_forces_at_n2500(solver, big):
     for r in range(2):
         Fo, eo = O.energy_force(om, d10, x[r].astype(np.float64), 1.0, 1.0, 0.85)
         scale = np.abs(Fo).max()
-        assert (np.abs(F[r] - Fo) <= 3e-4 * np.abs(Fo) + 3e-5 * scale).all()
+        assert (np.abs(F[r] - Fo) <= 2e-5 * np.abs(Fo) + 2e-6 * scale).all()
         assert np.allclose(e[r], eo, rtol=1e-6)
     assert (np.abs(F.sum(1)).max(1) < 5e-5 * np.abs(F).sum(1).max(1)).all()     # Newton's third law
 
