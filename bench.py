@@ -56,10 +56,18 @@ def cpu_baseline(IF, d10, model, fire, stages, budget_s=15.0):
         take = min(r[1], budget_steps - total)
         sample.append((r[0], take) + tuple(r[2:]))
         total += take
+    # whole replicas of the sampled schedule until the sample is >= ~10 s of CPU work
     t0 = time.perf_counter()
-    _, _, ev = O.run_schedule(om, d10, O.make_stages(sample), of, 82364, 0, x0=x)
-    dt = time.perf_counter() - t0
-    return ev / dt, f"1 replica of {WORKLOAD}, {ev} SA steps of the same schedule (hot/cool MD), fp64 oracle/c3d_oracle.c, 1 core, {dt:.1f} s"
+    ev, reps = 0, 0
+    while True:
+        _, _, e1 = O.run_schedule(om, d10, O.make_stages(sample), of, 82364, reps, x0=x)
+        ev += e1
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= 10.0 or reps >= 8:
+            break
+    return ev / dt, (f"{reps} replica(s) of {WORKLOAD}, {ev} SA steps of the same schedule (hot/cool MD + FIRE), "
+                     f"fp64 oracle/c3d_oracle.c, 1 core, {dt:.1f} s")
 
 
 def main():

@@ -342,3 +342,34 @@ def test_dg_embedding_matches_oracle(solver, O, cid):
     assert (rho0 < -0.5).all()
     solver.run()
     assert np.isfinite(solver.coords()).all()
+
+
+def test_degenerate_and_limit_sizes(solver):
+    """Edge cases: chains shorter than the restraint separation (no restraints at all), beads without
+    any restraint (all-zero IF rows), and the size guard."""
+    from chromosome3d_amd import C3DError, default_model, default_schedule, pipeline
+    solver.set_model(default_model())
+    rng = np.random.default_rng(3)
+    # N = 4 < SEPARATION: zero restraints, only the chain terms act
+    IF = rng.uniform(1, 100, size=(4, 4)); IF = IF + IF.T
+    d10 = pipeline.IF2dist_new(solver, IF)
+    assert solver.num_restraints == 0 and d10.shape == (4, 4)
+    solver.set_schedule(default_schedule(200), None, 0.0, 250)
+    solver.init_replicas(3, 82364, 0)
+    solver.run()
+    x = solver.coords()
+    b = np.linalg.norm(x[:, 1:] - x[:, :-1], axis=2)
+    assert np.isfinite(x).all() and np.abs(b - 3.8).max() < 0.3
+    # N = 40 with two beads that have no contact data at all (rows/cols of zeros, like unmappable bins)
+    IF, _ = __import__("tests.util", fromlist=["synthetic_if"]).synthetic_if(40, seed=5)
+    IF[[7, 8], :] = 0.0; IF[:, [7, 8]] = 0.0
+    d10 = pipeline.IF2dist_new(solver, IF)
+    assert (d10[7] == -10).all() and (d10[:, 8] == -10).all()
+    solver.init_replicas(2, 82364, 0)
+    solver.run()
+    assert np.isfinite(solver.coords()).all() and np.isfinite(solver.energies()).all()
+    # size guard of this build
+    with pytest.raises(C3DError, match="5120"):
+        solver.set_if_matrix(np.ones((5121, 5121)))
+    with pytest.raises(C3DError):
+        solver.set_if_matrix(np.ones((1, 1)))
