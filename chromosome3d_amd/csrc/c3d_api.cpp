@@ -170,9 +170,12 @@ c3d::DevStep dev_step(const c3d_ctx* c, int kind, float dt, float w_all, float w
     c3d::DevStep p;
     p.kind = kind; p.dt = dt; p.w_all = w_all;
     p.w_noe = w_all * c->model.s_noe;
+    p.w_noe2n = -2.0f * p.w_noe;
     p.w_rep4 = 4.0f * w_vdw * c->model.k_rep;
     const float rr = repel_s * c->model.r0_rep;
     p.rep_r2 = rr * rr;
+    p.inv_rep_r2 = rr > 0.0f ? 1.0f / p.rep_r2 : 0.0f;
+    p.w_rep4r2 = p.w_rep4 * p.rep_r2;
     p.t_bath = t_bath;
     return p;
 }

@@ -148,17 +148,33 @@ __device__ __forceinline__ void tile_prefetch(const DevModel& m, const float* __
         tv[r] = *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 256 * jb + 4 * lane);
 }
 
+// One pair term.  F_i += c * (x_i - x_j) with c = -(dE/dd)/d.  Written to minimise VALU issue slots
+// (this is the inner loop of the whole solver):
+//   r2 carries a +1e-12 guard inside the fma chain (no separate max);
+//   NOE, CNS-default tail (slope 2 rs): with u = (d - t)/d = 1 - t/d the clamp of the soft-square acts on
+//   u directly: -(dE/dd)/d = -2 w S min(u, rs/d)  (d itself is never formed);
+//   repel: max(0, R2 - r2) = R2 * clamp01(1 - r2/R2) is ONE v_fma_f32 with the clamp output modifier.
 template <int POT, bool GEN>
 __device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, float v, float dx, float dy, float dz,
                                           float& fx, float& fy, float& fz) {
-    const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
+    const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, 1e-12f)));
     const float rinv = __builtin_amdgcn_rsqf(r2);
-    const float d = r2 * rinv;
-    const float g = noe_grad<POT, GEN>(d - v, m);
-    float c = (v > 0.0f) ? -p.w_noe * g * rinv : 0.0f;   // v = target (A), 0 = no restraint
+    float s;   // (dE/dd) / (2 d) without the weights
+    if constexpr (!GEN) {
+        const float u = fmaf(-v, rinv, 1.0f);          // (d - t) / d
+        const float lim = m.rs * rinv;                 // rs / d
+        if constexpr (POT == 1) s = fminf(u, lim);
+        else if constexpr (POT == 0) s = fminf(fmaxf(u, -lim), lim);
+        else s = u;
+    } else {
+        s = 0.5f * noe_grad<POT, GEN>(r2 * rinv - v, m) * rinv;
+    }
+    float c = (v > 0.0f) ? p.w_noe2n * s : 0.0f;      // v = target (A), 0 = no restraint; w_noe2n = -2 w S
     // repel on EVERY column: padding beads are 1e4 A away (q = 0), the self term has dx = 0, and the
     // |i-j| < rep_sep neighbours are taken back out in the chain-term pass below
-    c = fmaf(p.w_rep4, fmaxf(p.rep_r2 - r2, 0.0f), c);
+    float q01;   // clamp01(1 - r2/R2): the clamp is an output modifier of the fma (hipcc has no builtin for it)
+    asm("v_fma_f32 %0, -%1, %2, 1.0 clamp" : "=v"(q01) : "v"(r2), "v"(p.inv_rep_r2));
+    c = fmaf(p.w_rep4r2, q01, c);                      // 4 w_vdw k_rep R2 * clamp01(1 - r2/R2)
     fx = fmaf(c, dx, fx);
     fy = fmaf(c, dy, fy);
     fz = fmaf(c, dz, fz);

@@ -38,8 +38,11 @@ struct DevStep {
     float dt;
     float w_all;     // weights * w
     float w_noe;     // w_all * s_noe
+    float w_noe2n;   // -2 * w_all * s_noe
     float w_rep4;    // 4 * w_vdw * k_rep
     float rep_r2;    // (repel_s * r0_rep)^2
+    float inv_rep_r2;// 1 / rep_r2
+    float w_rep4r2;  // w_rep4 * rep_r2
     float t_bath;
 };
 
