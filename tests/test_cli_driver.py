@@ -121,3 +121,24 @@ def test_batch_script_runs_every_matrix(built, tmp_path):
     for cid in ("chr21_1mb", "chr22_1mb"):
         assert (tmp_path / "out" / f"{cid}.log").exists()
         assert len(list((tmp_path / "out" / cid).glob(f"{cid}_matrix_model*.pdb"))) == 5
+
+
+def test_perl_driver_fails_loudly_without_gpu(built, tmp_path):
+    """Error convention of the reference (:281-288): iam.failed + die, through both binding routes."""
+    from chromosome3d_amd import lib
+    if lib.load().c3d_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    if shutil.which("perl") is None:
+        pytest.skip("no perl here")
+    drv = os.path.join(ROOT, "bin", "chromosome3D_amd.pl")
+    for force_cli in ("0", "1"):
+        od = tmp_path / f"o{force_cli}"
+        env = dict(os.environ)
+        env.pop("C3D_FORCE_CLI", None)
+        if force_cli == "1":
+            env["C3D_FORCE_CLI"] = "1"
+        out = subprocess.run(["perl", drv, "-i", MATRIX, "-o", str(od), "-m", "3"], capture_output=True, text=True, env=env)
+        assert out.returncode != 0
+        assert (od / "iam.failed").exists()
+        assert "no HIP device" in (out.stderr + out.stdout + open(od / "job.log").read() if (od / "job.log").exists() else out.stderr + out.stdout)
+        assert not list(od.glob("*_model*.pdb"))
