@@ -169,8 +169,7 @@ c3d::DevFire dev_fire(const c3d_ctx* c) {
 c3d::DevStep dev_step(const c3d_ctx* c, int kind, float dt, float w_all, float w_vdw, float repel_s, float t_bath) {
     c3d::DevStep p;
     p.kind = kind; p.dt = dt; p.w_all = w_all;
-    p.w_noe = w_all * c->model.s_noe;
-    p.w_noe2n = -2.0f * p.w_noe;
+    p.w_noe2n = -2.0f * w_all * c->model.s_noe;
     p.w_rep4 = 4.0f * w_vdw * c->model.k_rep;
     const float rr = repel_s * c->model.r0_rep;
     p.rep_r2 = rr * rr;
@@ -548,19 +547,14 @@ extern "C" int c3d_set_restraints(c3d_ctx* c, int n, int R, const int32_t* ri, c
     free_replica_buffers(c);
     set_dims(c, n);
     std::vector<float> enc((size_t)n * c->npad);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < c->npad; ++j) {
-            const int sep = std::abs(i - j);
-            enc[(size_t)i * c->npad + j] = c3d::encode_target_host(0.0f, j < n && sep >= c->model.rep_sep);
-        }
+    std::fill(enc.begin(), enc.end(), 0.0f);
     for (int k = 0; k < R; ++k) {
         const int i = ri[k] - 1, j = rj[k] - 1;
         if (i < 0 || j < 0 || i >= n || j >= n || i == j) return fail(C3D_ERR_INVALID, "c3d_set_restraints: index out of range");
         if (rt10[k] <= 0) continue;
         const float t = (float)((double)rt10[k] / 10.0);
-        const bool rep = std::abs(i - j) >= c->model.rep_sep;
-        enc[(size_t)i * c->npad + j] = c3d::encode_target_host(t, rep);
-        enc[(size_t)j * c->npad + i] = c3d::encode_target_host(t, rep);
+        enc[(size_t)i * c->npad + j] = c3d::encode_target_host(t);
+        enc[(size_t)j * c->npad + i] = c3d::encode_target_host(t);
     }
     int rc = upload_targets(c, enc);
     if (rc) return rc;
@@ -806,7 +800,7 @@ extern "C" int c3d_eval(c3d_ctx* c, float w_all, float w_vdw, float repel_s, flo
         if (rc) return rc;
     }
     if (e) {
-        hipError_t err = c3d::launch_energy(m, p, c->buf, c->parity, c->model.s_noe, c->model.k_rep, 0, c->stream);
+        hipError_t err = c3d::launch_energy(m, p, c->buf, c->parity, c->model.s_noe, c->model.k_rep, c->stream);
         if (err != hipSuccess) return fail(C3D_ERR_HIP, std::string("energy launch: ") + hipGetErrorString(err));
         std::vector<double> h((size_t)4 * c->nrep);
         HIP_TRY(hipMemcpyAsync(h.data(), c->buf.E, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));

@@ -58,11 +58,6 @@ __device__ __forceinline__ float wave_sum(float v) {   // total in every lane
     v += dpp_mov<0x128>(v);         // row_ror:8
     return xrow_sum(v);
 }
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 // sum over the low RPW lanes of each quad (RPW in {1,2,4}); valid in lane 0
 template <int RPW>
 __device__ __forceinline__ float quad_sum(float v) {
@@ -449,7 +444,7 @@ hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, c
 // Test / scoring hook: forces only, through the same tile_forces<> as the step kernel
 // ---------------------------------------------------------------------------------------------
 template <int POT, bool GEN>
-__global__ __launch_bounds__(kBlock) void k_eval_forces(const DevModel m, const DevStep p,
+__global__ __launch_bounds__(kEvalBlock) void k_eval_forces(const DevModel m, const DevStep p,
                                                        const float* __restrict__ tgt, const float* __restrict__ xin,
                                                        float* __restrict__ fout) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -458,15 +453,15 @@ __global__ __launch_bounds__(kBlock) void k_eval_forces(const DevModel m, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npad = m.npad;
     const size_t roff = (size_t)rep * 3 * npad;
-    const int row0 = tile * kTileRows + wave * kRowsPerWave;
-    float4 tv[kRowsPerWave];
-    tile_prefetch<kRowsPerWave>(m, tgt, row0, lane, 0, tv);
-    for (int b = tid; b < 3 * npad; b += kBlock) smem[b] = xin[roff + b];
+    const int row0 = tile * kTileRows + wave * kEvalRowsPerWave;
+    float4 tv[kEvalRowsPerWave];
+    tile_prefetch<kEvalRowsPerWave>(m, tgt, row0, lane, 0, tv);
+    for (int b = tid; b < 3 * npad; b += kEvalBlock) smem[b] = xin[roff + b];
     __syncthreads();
     float Fx, Fy, Fz;
-    tile_forces<POT, GEN, kRowsPerWave>(m, p, tgt, smem, smem + npad, smem + 2 * npad, row0, lane, tv, Fx, Fy, Fz);
+    tile_forces<POT, GEN, kEvalRowsPerWave>(m, p, tgt, smem, smem + npad, smem + 2 * npad, row0, lane, tv, Fx, Fy, Fz);
     const int row = row0 + lane;
-    if (lane < kRowsPerWave && row < m.n) {
+    if (lane < kEvalRowsPerWave && row < m.n) {
         fout[roff + row] = Fx;
         fout[roff + npad + row] = Fy;
         fout[roff + 2 * npad + row] = Fz;
@@ -476,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void k_eval_forces(const DevModel m, const 
 hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float* Fout,
                               bool general_tail, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)3 * m.npad;
-    const dim3 g(grid_blocks(m)), blk(kBlock);
+    const dim3 g(grid_blocks(m)), blk(kEvalBlock);
 #define C3D_EVAL(POT, GEN) hipLaunchKernelGGL((k_eval_forces<POT, GEN>), g, blk, lds, s, m, p, b.tgt, b.X[parity], Fout)
     if (!general_tail) {
         if (m.noe_pot == 0) C3D_EVAL(0, false); else if (m.noe_pot == 1) C3D_EVAL(1, false); else C3D_EVAL(2, false);
@@ -535,7 +530,7 @@ __global__ __launch_bounds__(256) void k_energy(const DevModel m, const float s_
 }
 
 hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe, float k_rep,
-                         int, hipStream_t s) {
+                         hipStream_t s) {
     hipLaunchKernelGGL(k_energy, dim3(m.nrep), dim3(256), 0, s, m, s_noe, k_rep, p.rep_r2, b.tgt, b.X[parity], b.E);
     return hipGetLastError();
 }

@@ -9,11 +9,11 @@ namespace c3d {
 constexpr float kBoltz = 0.0019872f;  // kcal/mol/K (X-PLOR/CNS AKMA)
 constexpr float kAccel = 418.4f;      // kcal/mol/A/amu -> A/ps^2
 
-// rows of the pair matrix owned by one workgroup = kWaves * kRowsPerWave
-constexpr int kWaves = 2;
-constexpr int kRowsPerWave = 4;
-constexpr int kTileRows = kWaves * kRowsPerWave;
-constexpr int kBlock = kWaves * 64;
+// rows of the pair matrix owned by one workgroup of the step kernel (waves per workgroup = kTileRows / rpw)
+constexpr int kTileRows = 8;
+// the forces-only test hook runs the same tile with 4 rows per wave
+constexpr int kEvalRowsPerWave = 4;
+constexpr int kEvalBlock = 64 * kTileRows / kEvalRowsPerWave;
 
 // far-away coordinates for the padding beads j in [n, npad): no NOE (target 0), repel term vanishes
 constexpr float kPadCoord = 1.0e4f;
@@ -37,7 +37,6 @@ struct DevStep {
     int kind;        // 0 MD T-coupling, 1 MD velocity rescale, 2 FIRE step, 3 first FIRE step of a stage, 4 MD begin
     float dt;
     float w_all;     // weights * w
-    float w_noe;     // w_all * s_noe
     float w_noe2n;   // -2 * w_all * s_noe
     float w_rep4;    // 4 * w_vdw * k_rep
     float rep_r2;    // (repel_s * r0_rep)^2
@@ -78,7 +77,7 @@ hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, c
 hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float* Fout,
                               bool general_tail, hipStream_t s);
 hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe,
-                         float k_rep, int min_sep_unused, hipStream_t s);
+                         float k_rep, hipStream_t s);
 hipError_t launch_centre(const DevModel& m, const DevBuffers& b, int parity, hipStream_t s);
 // K1: IF (n*n fp64, device) -> dist10 (n*n int32, device) and encoded targets (n*npad, device)
 hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, double K, int min_sep, int rep_sep,
@@ -91,6 +90,6 @@ hipError_t launch_dg_embed(const float* tgt, int n, int npad, int nrep, float b0
                            float* x1, hipStream_t s);
 
 // Target matrix entry: NOE target in Angstrom, 0 = no restraint (host c3d_set_restraints and K1).
-inline float encode_target_host(float t, bool) { return t > 0 ? t : 0.0f; }
+inline float encode_target_host(float t) { return t > 0 ? t : 0.0f; }
 
 }  // namespace c3d
