@@ -106,15 +106,23 @@ print "\nNOE_SATISFIED(+-${DISTRELAX}A)  SUM_OF_DEVIATIONS>= 0.2  PDB\n";
 foreach my $pdb (sort { $e_noe{$b} <=> $e_noe{$a} || $a cmp $b } keys %e_noe) {
 	my %xyz = read_ca($pdb);
 	my ($count, $total, $sum_dev) = (0, 0, 0.0);
+	my (@viol, @ok);   # rows of contact_violation.txt (reference :475-483: violated rows first)
 	foreach my $r (@tbl) {
 		my ($i, $j, $t) = @$r;
 		my $d = sprintf "%.3f", sqrt(($xyz{$i}[0]-$xyz{$j}[0])**2 + ($xyz{$i}[1]-$xyz{$j}[1])**2 + ($xyz{$i}[2]-$xyz{$j}[2])**2);
-		$count++ if $d < $t + $DISTRELAX;
-		$count-- if $d < $t - $DISTRELAX;
+		my ($flag, $deviation) = (1, $d - $t);
+		if ($d < $t + $DISTRELAX) { $count++; $flag = 0; $deviation = 0.0; }
+		if ($d < $t - $DISTRELAX) { $count--; $flag = 1; $deviation = -($t - $d); }
 		$sum_dev += $d - $t if $d > $t + 0.2;
 		$sum_dev += $t - $d if $d < $t - 0.2;
 		$total++;
+		my $row = sprintf "%3s\t%.2f\t%.2f # assign45  resid %3d and name ca   resid %3d and name ca  %.2f 0.00 0.00", $flag, $deviation, $d, $i, $j, $t;
+		if ($flag) { push @viol, $row } else { push @ok, $row }
 	}
+	open my $vf, ">>", "contact_violation.txt" or die $!;
+	print $vf "#NOE violation check; $pdb against contact.tbl\n#violation-flag, deviation, actual-measurement, Input-NOE-restraint\n";
+	print $vf "$_\n" foreach (@viol, @ok);
+	close $vf;
 	printf "%-9s             %-9s                %-25s\n", "$count/$total", (sprintf "%.2f", $sum_dev), basename($pdb, ".pdb");
 	print $log "$pdb\n".join("", grep { /^REMARK/ } do { open my $f, "<", $pdb or die $!; <$f> })."\n";
 }

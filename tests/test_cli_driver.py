@@ -84,6 +84,14 @@ def test_perl_driver_same_cli_and_outputs(built, tmp_path):
         assert [m.name for m in models] == [f"{cid}_model{k}.pdb" for k in range(1, 6)]
         assert len(list(od.glob(f"{cid}_*.pdb"))) == 7
         assert "Restraints : 528 lines in tbl file" in out.stdout and "model1.pdb <=" in out.stdout
+        # contact_violation.txt in the reference's row format (:475-483; golden rows from the reference itself)
+        import re
+        vrows = open(od / "contact_violation.txt").read().splitlines()
+        assert len(vrows) == 7 * (2 + 528) and vrows[0].startswith("#NOE violation check;")
+        gold_fmt = open(os.path.join(GOLD, "chr21_1mb.contact_violation.txt")).read().splitlines()[2]
+        pat = re.compile(r"^  [01]\t-?\d+\.\d\d\t\d+\.\d\d # assign45  resid +\d+ and name ca   resid +\d+ and name ca  \d+\.\d0 0\.00 0\.00$")
+        assert pat.match(gold_fmt), gold_fmt
+        assert all(pat.match(r) for r in vrows[2:530])
         # ranking = ascending int(REMARK noe)
         e = []
         for m in models:
