@@ -817,6 +817,55 @@ extern "C" int c3d_get_energies(c3d_ctx* c, double* e) {
     return c3d_eval(c, 1.0f, 1.0f, repel_s, nullptr, e);
 }
 
+// K6 on the device: count_satisfied_tbl_rows / sum_noe_dev (:447-485, :581-600) and, when IF is given,
+// spearman_IF_pdb.pl's coefficient for every replica, from the coordinates resident on the GPU.
+extern "C" int c3d_score_replicas(c3d_ctx* c, const double* IF, int range, int32_t* satisfied, double* sum_dev, double* rho) {
+    if (!c || range < 1) return fail(C3D_ERR_INVALID, "c3d_score_replicas: bad arguments");
+    if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_score_replicas: call c3d_init_replicas first");
+    if (rho && !IF) return fail(C3D_ERR_INVALID, "c3d_score_replicas: the Spearman coefficient needs the IF matrix");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = c->n, nrep = c->nrep;
+    const unsigned nbins = 1u << 18;      // distances up to 262 A in thousandths
+    std::vector<double> rankA;
+    size_t m = 0;
+    double ma = 0, saa = 0;
+    DevTmp<double> d_rank, d_xr, d_part;
+    DevTmp<unsigned> d_hist, d_below;
+    DevTmp<int> d_ovf;
+    if (IF && rho) {
+        c3d::if_pair_ranks(IF, n, range, rankA, m, ma, saa);
+        if (m < 2) return fail(C3D_ERR_INVALID, "c3d_score_replicas: range leaves no pairs");
+        HIP_TRY(hipMalloc(&d_rank.p, sizeof(double) * rankA.size()));
+        HIP_TRY(hipMemcpyAsync(d_rank.p, rankA.data(), sizeof(double) * rankA.size(), hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipMalloc(&d_xr.p, sizeof(double) * 3 * (size_t)n * nrep));
+    HIP_TRY(hipMalloc(&d_part.p, sizeof(double) * 4 * (size_t)n * nrep));
+    HIP_TRY(hipMalloc(&d_hist.p, sizeof(unsigned) * (size_t)nbins * nrep));
+    HIP_TRY(hipMalloc(&d_below.p, sizeof(unsigned) * (size_t)nbins * nrep));
+    HIP_TRY(hipMalloc(&d_ovf.p, sizeof(int)));
+    const double mb = 0.5 * ((double)m + 1.0);     // mean of the ranks 1..m, ties or not
+    hipError_t e = c3d::launch_score(c->buf.X[c->parity], c->buf.tgt, d_rank.p, n, c->npad, nrep, range, c->model.min_sep, nbins, ma,
+                                     mb, 0.5, d_xr.p, d_hist.p, d_below.p, d_part.p, d_ovf.p, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("score launch: ") + hipGetErrorString(e));
+    std::vector<double> part((size_t)4 * n * nrep);
+    int ovf = 0;
+    HIP_TRY(hipMemcpyAsync(part.data(), d_part.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&ovf, d_ovf.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ovf) return fail(C3D_ERR_INVALID, "c3d_score_replicas: a pair distance exceeds 262 A (device histogram range)");
+    for (int r = 0; r < nrep; ++r) {
+        double sab = 0, sbb = 0, sat = 0, dev = 0;
+        for (int i = 0; i < n; ++i) {    // fixed order: deterministic
+            const double* q = part.data() + ((size_t)r * n + i) * 4;
+            sab += q[0]; sbb += q[1]; sat += q[2]; dev += q[3];
+        }
+        if (satisfied) satisfied[r] = (int32_t)llround(sat);
+        if (sum_dev) sum_dev[r] = dev;
+        if (rho) rho[r] = sab / sqrt(saa * sbb);
+    }
+    return C3D_OK;
+}
+
 extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
     if (!c || !rank) return fail(C3D_ERR_INVALID, "c3d_rank: null argument");
     std::vector<double> e((size_t)3 * std::max(c->nrep, 1));

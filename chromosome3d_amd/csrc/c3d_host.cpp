@@ -286,6 +286,25 @@ static void avg_ranks(const std::vector<double>& v, std::vector<double>& r) {
     }
 }
 
+void c3d::if_pair_ranks(const double* IF, int n, int range, std::vector<double>& rank_matrix, size_t& m, double& mean_rank, double& saa) {
+    std::vector<double> a, ra;
+    std::vector<size_t> pos;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            if (std::abs(i - j) < range) continue;
+            a.push_back(IF[(size_t)i * n + j]);
+            pos.push_back((size_t)i * n + j);
+        }
+    m = a.size();
+    rank_matrix.assign((size_t)n * n, 0.0);
+    mean_rank = 0; saa = 0;
+    if (m == 0) return;
+    avg_ranks(a, ra);
+    for (size_t k = 0; k < m; ++k) { rank_matrix[pos[k]] = ra[k]; mean_rank += ra[k]; }
+    mean_rank /= (double)m;
+    for (size_t k = 0; k < m; ++k) saa += (ra[k] - mean_rank) * (ra[k] - mean_rank);
+}
+
 // Spearman for M models of one matrix: the IF ranks are computed once; distances are integers in
 // thousandths of an Angstrom (the "%.3f" rounding of spearman_IF_pdb.pl:47), so their average
 // ranks come from a counting pass instead of a sort.

@@ -89,6 +89,11 @@ hipError_t launch_dg_embed(const float* tgt, int n, int npad, int nrep, float b0
                            uint32_t first_replica, int iters, const float* v0, float* U, float* L, float* D2, float* x0,
                            float* x1, hipStream_t s);
 
+// K6 (c3d_score.hip): satisfied / sum-of-deviations / Spearman partial sums for every replica
+hipError_t launch_score(const float* xin, const float* tgt, const double* rankA, int n, int npad, int nrep, int range, int min_sep,
+                        unsigned nbins, double ma, double mb, double relax, double* xr, unsigned* hist, unsigned* below,
+                        double* partial, int* overflow, hipStream_t s);
+
 // Target matrix entry: NOE target in Angstrom, 0 = no restraint (host c3d_set_restraints and K1).
 inline float encode_target_host(float t) { return t > 0 ? t : 0.0f; }
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "c3d_last_timing": (_i, [_vp, _dp, C.POINTER(_l), C.POINTER(_l)]),
     "c3d_eval": (_i, [_vp, _f, _f, _f, _fp, _dp]),
     "c3d_get_energies": (_i, [_vp, _dp]),
+    "c3d_score_replicas": (_i, [_vp, _dp, _i, _i32p, _dp, _dp]),
     "c3d_rank": (_i, [_vp, _i32p]),
     "c3d_parse_if_file": (_i, [C.c_char_p, C.POINTER(_dp), C.POINTER(_i)]),
     "c3d_free": (None, [_vp]),

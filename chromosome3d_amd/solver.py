@@ -152,6 +152,16 @@ class Solver:
         _l.check(self._L.c3d_get_energies(self._h, _l.dptr(e)))
         return e
 
+    def score(self, IF=None, rng=3):
+        """K6 on the device: (satisfied[M], sum_dev[M], spearman[M] or None) at the current coordinates."""
+        sat = np.empty(self.nrep, dtype=np.int32)
+        dev = np.empty(self.nrep, dtype=np.float64)
+        rho = np.empty(self.nrep, dtype=np.float64) if IF is not None else None
+        IFc = np.ascontiguousarray(IF, dtype=np.float64) if IF is not None else None
+        _l.check(self._L.c3d_score_replicas(self._h, _l.dptr(IFc) if IF is not None else None, rng, _l.i32ptr(sat), _l.dptr(dev),
+                                            _l.dptr(rho) if IF is not None else None))
+        return sat, dev, rho
+
     def rank(self):
         r = np.empty(self.nrep, dtype=np.int32)
         _l.check(self._L.c3d_rank(self._h, _l.i32ptr(r)))

@@ -137,6 +137,11 @@ int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* lau
 int c3d_eval(c3d_ctx* ctx, float w_all, float w_vdw, float repel_s, float* F, double* e);
 /* per replica: e[3*r + {0,1,2}] = E_noe, E_bond(+angle), E_repel at the final weights */
 int c3d_get_energies(c3d_ctx* ctx, double* e);
+/* K6 on the device, for every replica at its current coordinates: the restraint-satisfaction count and
+ * the sum of deviations of chromosome3D.pl:447-485 / :581-600 (relax 0.5 A, threshold 0.2 A) and, if IF
+ * (the n*n matrix given to c3d_set_if_matrix) and rho are non-NULL, Spearman(IF, d) over |i-j| >= range
+ * as spearman_IF_pdb.pl:42-70 defines it.  Any output pointer may be NULL. */
+int c3d_score_replicas(c3d_ctx* ctx, const double* IF, int range, int32_t* satisfied, double* sum_dev, double* rho);
 /* rank[k] = replica index with the k-th lowest int(E_noe) (chromosome3D.pl:796-802,822-828);
  * ties broken by replica id. */
 int c3d_rank(c3d_ctx* ctx, int32_t* rank);

@@ -373,3 +373,30 @@ def test_degenerate_and_limit_sizes(solver):
         solver.set_if_matrix(np.ones((5121, 5121)))
     with pytest.raises(C3DError):
         solver.set_if_matrix(np.ones((1, 1)))
+
+
+@pytest.mark.parametrize("cid", ["chr21_1mb", "chr19_500kb", "chr1_500kb"])
+def test_device_scoring_equals_host_scoring(solver, cid):
+    """K6: satisfied / sum-of-deviations / Spearman computed on the GPU from resident coordinates equal
+    the host implementation that is pinned to the reference's known answers (integers exact, fp64 sums
+    to rounding)."""
+    from chromosome3d_amd import default_model, default_schedule, pipeline
+    IF = load_if(cid)
+    solver.set_model(default_model())
+    d10 = pipeline.IF2dist_new(solver, IF)
+    rows = pipeline.restraints_from_dist10(d10)
+    solver.set_schedule(default_schedule(300), None, 0.0, 250)
+    solver.init_replicas(5, 82364, 0)
+    for phase in ("start", "annealed"):
+        if phase == "annealed":
+            solver.run()
+        x = solver.coords()
+        sat, dev, rho = solver.score(IF, 3)
+        host_rho = pipeline.spearman_IF_models(IF, x)
+        for r in range(5):
+            hs, hd = pipeline.assess(x[r], rows)
+            assert sat[r] == hs
+            assert abs(dev[r] - hd) <= 1e-10 * max(1.0, abs(hd))
+        assert np.allclose(rho, host_rho, rtol=0, atol=1e-12)
+    sat2, dev2, none = solver.score(None)
+    assert none is None and np.array_equal(sat2, sat) and np.array_equal(dev2, dev)
