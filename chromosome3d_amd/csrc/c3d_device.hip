@@ -7,16 +7,18 @@
 //                                      thermostat, COM removal    (deck :1646-1700, :1729-1782)
 //   K4  k_step<> (FIRE kinds)          K2 + FIRE minimiser update (deck :1790-1803, L-BFGS there)
 //   K6  k_energy                       fp64 energies per replica  (REMARK noe, :602-618)
+//       (assessment / Spearman scoring of resident replicas: c3d_score.hip)
 //
-// One launch = one SA step for every replica.  A workgroup (4 waves) owns 16 consecutive rows of
-// one replica's N x N pair matrix; the kernel boundary is the only inter-workgroup
+// One launch = one SA step for every replica of a group.  A workgroup (kTileRows / RPW waves, RPW
+// rows per wave; 4 waves x 2 rows by default) owns kTileRows = 8 consecutive rows of one replica's
+// N x N pair matrix, lanes run along the columns, 4 columns per lane per block; the kernel boundary is the only inter-workgroup
 // synchronisation (no in-launch hand-offs, no atomics): every workgroup reads the previous
 // step's buffers (parity p) and writes only its own rows of the next (parity p^1).  Global
 // reductions a step needs (kinetic energy, COM velocity, FIRE power/norms) are carried as
 // per-tile partial sums written by step k and summed, in a fixed order, in the prologue of
 // step k+1 by every workgroup — deterministic and independent of the GPU count.
 //
-// No MFMA: the work is an O(N^2) distance reduction (~25 VALU ops per pair), not a contraction.
+// No MFMA: the work is an O(N^2) distance reduction (~19 VALU issue slots per pair), not a contraction.
 #include "c3d_internal.h"
 
 namespace c3d {
