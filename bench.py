@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
     ap.add_argument("--groups", type=int, default=0, help="replica groups on separate streams (0 = library default)")
+    ap.add_argument("--resident", type=int, default=-1, help="1/0: resident multi-step kernel on/off (-1 = library default)")
     ap.add_argument("--rpw", type=int, default=0, help="rows per wave of the step kernel (tuning knob; 0 = library default)")
     args = ap.parse_args()
 
@@ -119,6 +120,8 @@ def main():
         s.set_option("rows_per_wave", args.rpw)
     if args.groups:
         s.set_option("replica_groups", args.groups)
+    if args.resident >= 0:
+        s.set_option("resident", args.resident)
     L = s.schedule_length
 
     def sync_all():

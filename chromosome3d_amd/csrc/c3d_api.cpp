@@ -97,6 +97,8 @@ struct c3d_ctx {
     int rpw = 2;
     int stage_dma = 1;
     int graph_chunk = 256;
+    bool resident = false;                 // multi-step resident kernel where the problem fits (c3d_resident.hip)
+    int resident_min_ops = 4;              // shorter ranges go step by step
 
     std::vector<int32_t> h_dist10;   // n*n, from K1 (empty when restraints came from a tbl)
     c3d::DevBuffers buf{};
@@ -109,6 +111,18 @@ struct c3d_ctx {
     int parity = 0;
     long steps_done = 0;
     std::map<std::tuple<long, int, int, int>, hipGraphExec_t> graphs;
+
+    // resident kernel state: device copy of the program's step parameters, the two pointer blocks (by
+    // parity), the tile-record hand-off area and the timeout word
+    c3d::DevStep* d_program = nullptr;
+    bool program_uploaded = false;
+    c3d::AnnealIO* d_io = nullptr;         // [2]
+    void* d_rec = nullptr;
+    size_t rec_bytes = 0;
+    unsigned* d_tmo = nullptr;
+    bool resident_pending = false;         // a resident launch has not had its timeout word checked yet
+    int resident_cap = -1;                 // workgroups per CU of the resident kernel (-1: not queried)
+    int num_cus = 0;
 
     double last_ms = 0;
     long last_steps = 0, last_launches = 0;
@@ -127,6 +141,9 @@ void free_replica_buffers(c3d_ctx* c) {
         c->buf.X[k] = c->buf.V[k] = c->buf.P[k] = nullptr;
         c->buf.S[k] = nullptr;
     }
+    if (c->d_rec) hipFree(c->d_rec);
+    if (c->d_io) hipFree(c->d_io);
+    c->d_rec = nullptr; c->d_io = nullptr; c->rec_bytes = 0;
     if (c->buf.Vinit) hipFree(c->buf.Vinit);
     if (c->buf.E) hipFree(c->buf.E);
     if (c->d_feval) hipFree(c->d_feval);
@@ -196,6 +213,8 @@ void build_program(c3d_ctx* c) {
         prev_kind = st.kind;
     }
     c->pc = 0;
+    c->program_uploaded = false;
+    c->resident_cap = -1;
     drop_graphs(c);
 }
 
@@ -250,9 +269,61 @@ int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
     return C3D_OK;
 }
 
+// Can the ops run as one resident launch?  The model must fit the kernel (npad <= 1024) and every workgroup
+// (replica x tile) must be resident at once.
+bool resident_ok(c3d_ctx* c) {
+    if (!c->resident || !c->d_rec) return false;
+    const c3d::DevModel m = dev_model(c);
+    if (!c3d::anneal_supported(m)) return false;
+    if (c->resident_cap < 0) {
+        int cap = 0;
+        if (c3d::anneal_blocks_per_cu(m, general_tail(m), &cap) != hipSuccess) cap = 0;
+        c->resident_cap = cap;
+    }
+    return (long)c->nrep * c->ntiles <= (long)c->resident_cap * c->num_cus;
+}
+
+int run_resident(c3d_ctx* c, size_t nops) {
+    if (!c->program_uploaded) {
+        if (c->d_program) { hipFree(c->d_program); c->d_program = nullptr; }
+        std::vector<c3d::DevStep> h(c->program.size());
+        for (size_t k = 0; k < h.size(); ++k) h[k] = c->program[k].p;
+        HIP_TRY(hipMalloc(&c->d_program, sizeof(c3d::DevStep) * h.size()));
+        HIP_TRY(hipMemcpy(c->d_program, h.data(), sizeof(c3d::DevStep) * h.size(), hipMemcpyHostToDevice));
+        c->program_uploaded = true;
+    }
+    const c3d::DevModel m = dev_model(c);
+    HIP_TRY(hipMemsetAsync(c->d_rec, 0, c->rec_bytes, c->stream));
+    hipError_t e = c3d::launch_anneal(m, dev_fire(c), c->d_io + c->parity, c->buf.tgt, general_tail(m), c->d_rec,
+                                      c->d_program + c->pc, (int)nops, c->d_tmo, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("resident launch: ") + hipGetErrorString(e));
+    c->resident_pending = true;
+    c->parity ^= 1;
+    for (size_t k = 0; k < nops; ++k)
+        if (c->program[c->pc + k].counted) { ++c->steps_done; ++c->last_steps; }
+    c->last_launches += 1;
+    c->pc += nops;
+    return C3D_OK;
+}
+
+// after a synchronisation: did a resident launch give up waiting for a tile record?
+int check_resident(c3d_ctx* c) {
+    if (!c->resident_pending) return C3D_OK;
+    c->resident_pending = false;
+    unsigned t = 0;
+    HIP_TRY(hipMemcpy(&t, c->d_tmo, sizeof(t), hipMemcpyDeviceToHost));
+    if (t) {
+        HIP_TRY(hipMemset(c->d_tmo, 0, sizeof(t)));
+        return fail(C3D_ERR_HIP, "resident anneal kernel: a tile waited ~2 s for its replica's records (workgroups not co-resident; "
+                                 "set option resident=0)");
+    }
+    return C3D_OK;
+}
+
 // run program ops [pc, pc + nops): eager or via cached graphs; every replica group advances on its
 // own stream (fork from / join into stream 0 around the call)
 int run_ops(c3d_ctx* c, size_t nops) {
+    if (nops >= (size_t)c->resident_min_ops && nops < (size_t)INT32_MAX && resident_ok(c)) return run_resident(c, nops);
     const int G = active_groups(c);
     if (G > 1) {
         HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
@@ -322,7 +393,7 @@ int end_timing(c3d_ctx* c) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
-    return C3D_OK;
+    return check_resident(c);
 }
 
 // max over replicas of the RMS force from the FIRE partial sums of the current parity
@@ -417,6 +488,7 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
         return fail(C3D_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libc3d is built for gfx950 only");
     c3d_ctx* c = new c3d_ctx();
     c->device = device;
+    c->num_cus = prop.multiProcessorCount;
     c3d_default_model(&c->model);
     c3d_default_fire(&c->fire);
     c->stages.resize(c3d_default_schedule(nullptr, 0, 3000));
@@ -428,8 +500,9 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     for (int g = 1; ok && g < c3d_ctx::kMaxGroups; ++g)
         ok = hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_tmo, 16) == hipSuccess && hipMemset(c->d_tmo, 0, 16) == hipSuccess;
     if (!ok) {
-        delete c;
+        c3d_destroy(c);
         return fail(C3D_ERR_HIP, "cannot create HIP stream/events");
     }
     *out = c;
@@ -443,6 +516,8 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
     drop_graphs(c);
     free_replica_buffers(c);
     if (c->buf.tgt) hipFree(c->buf.tgt);
+    if (c->d_program) hipFree(c->d_program);
+    if (c->d_tmo) hipFree(c->d_tmo);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (int g = 1; g < c3d_ctx::kMaxGroups; ++g) {
@@ -493,6 +568,8 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         drop_graphs(c);
         return C3D_OK;
     }
+    if (!strcmp(key, "resident")) { c->resident = value != 0; return C3D_OK; }
+    if (!strcmp(key, "resident_min_ops")) { c->resident_min_ops = value < 1 ? 1 : (int)value; return C3D_OK; }
     if (!strcmp(key, "stage_dma")) { c->stage_dma = value != 0; drop_graphs(c); return C3D_OK; }
     if (!strcmp(key, "graph_chunk")) {
         if (value < 8) return fail(C3D_ERR_INVALID, "graph_chunk must be >= 8");
@@ -592,6 +669,16 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
         HIP_TRY(hipMalloc(&c->buf.Vinit, sizeof(float) * nf));
         HIP_TRY(hipMalloc(&c->buf.E, sizeof(double) * 4 * nrep));
         HIP_TRY(hipMalloc(&c->d_feval, sizeof(float) * nf));
+        // resident kernel: hand-off records and the two pointer blocks (one per step parity)
+        {
+            c3d::DevModel m = dev_model(c);
+            m.nrep = nrep;
+            c->rec_bytes = c3d::anneal_record_bytes(m);
+            HIP_TRY(hipMalloc(&c->d_rec, c->rec_bytes));
+            const c3d::AnnealIO io[2] = {c3d::anneal_io(c->buf, 0), c3d::anneal_io(c->buf, 1)};
+            HIP_TRY(hipMalloc(&c->d_io, sizeof(io)));
+            HIP_TRY(hipMemcpy(c->d_io, io, sizeof(io), hipMemcpyHostToDevice));
+        }
         c->have_replicas = true;
     }
     // random coil (step b0) and Maxwell(0.5 K) velocities (deck :1646-1648), Philox keyed (seed, replica)

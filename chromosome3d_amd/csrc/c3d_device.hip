@@ -19,7 +19,7 @@
 // step k+1 by every workgroup — deterministic and independent of the GPU count.
 //
 // No MFMA: the work is an O(N^2) distance reduction (~19 VALU issue slots per pair), not a contraction.
-#include "c3d_internal.h"
+#include "c3d_step_core.h"
 
 namespace c3d {
 
@@ -35,71 +35,6 @@ __device__ unsigned long long g_stamps[16];
 #define C3D_STAMP(k) do { } while (0)
 #endif
 
-// ---------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------
-// Wave64 reductions on the VALU only (no ds_bpermute / LDS crossbar round trips):
-//   lanes ^1, ^2      v_add_f32_dpp quad_perm
-//   lanes -4, -8      v_add_f32_dpp row_ror:4 / row_ror:8   (sum of the 16-lane row, position kept)
-//   rows ^1, halves   v_permlane16_swap / v_permlane32_swap  (gfx950) + v_add
-// gfx9 DPP controls: quad_perm[a,b,c,d] = a|b<<2|c<<4|d<<6, row_ror:n = 0x120+n.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float xrow_sum(float v) {   // + the other three 16-lane rows, every lane
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
-__device__ __forceinline__ float wave_sum(float v) {   // total in every lane
-    v += dpp_mov<0xB1>(v);          // lanes ^1
-    v += dpp_mov<0x4E>(v);          // lanes ^2
-    v += dpp_mov<0x124>(v);         // row_ror:4
-    v += dpp_mov<0x128>(v);         // row_ror:8
-    return xrow_sum(v);
-}
-// sum over the low RPW lanes of each quad (RPW in {1,2,4}); valid in lane 0
-template <int RPW>
-__device__ __forceinline__ float quad_sum(float v) {
-    if constexpr (RPW >= 2) v += dpp_mov<0xB1>(v);
-    if constexpr (RPW >= 4) v += dpp_mov<0x4E>(v);
-    return v;
-}
-// Transposing reduction: a[r] is this lane's partial sum for row r.  Returns, in every lane l, the
-// sum over all 64 lanes of a[l & (RPW-1)]: the row selection rides on the first butterfly levels
-// (lane parity picks which row a lane keeps), every later level preserves lane & 3.
-template <int RPW>
-__device__ __forceinline__ float reduce_rows(const float (&a)[RPW], int lane) {
-    static_assert(RPW == 1 || RPW == 2 || RPW == 4, "rows per wave must be 1, 2 or 4");
-    float k;
-    if constexpr (RPW == 1) {
-        k = a[0];
-        k += dpp_mov<0xB1>(k);
-        k += dpp_mov<0x4E>(k);
-    } else if constexpr (RPW == 2) {
-        const bool b0 = lane & 1;
-        k = b0 ? a[1] : a[0];
-        const float s = b0 ? a[0] : a[1];
-        k += dpp_mov<0xB1>(s);
-        k += dpp_mov<0x4E>(k);
-    } else {
-        const bool b0 = lane & 1, b1 = lane & 2;
-        float k01 = b0 ? a[1] : a[0];
-        const float s01 = b0 ? a[0] : a[1];
-        float k23 = b0 ? a[3] : a[2];
-        const float s23 = b0 ? a[2] : a[3];
-        k01 += dpp_mov<0xB1>(s01);
-        k23 += dpp_mov<0xB1>(s23);
-        k = b1 ? k23 : k01;
-        const float s = b1 ? k01 : k23;
-        k += dpp_mov<0x4E>(s);
-    }
-    k += dpp_mov<0x124>(k);
-    k += dpp_mov<0x128>(k);
-    return xrow_sum(k);
-}
 
 // XCD-aware block -> (tile, replica) map.  Blocks b and b+8 share an XCD (round-robin dispatch,
 // a speed assumption only): every workgroup that reads row-tile t of the target matrix gets the
@@ -113,135 +48,6 @@ __device__ __forceinline__ bool block_to_tile(const DevModel& m, int& tile, int&
 }
 inline int grid_blocks(const DevModel& m) { return 8 * ((m.ntiles + 7) / 8) * m.nrep_g; }
 
-template <int POT, bool GEN>
-__device__ __forceinline__ float noe_grad(float delta, const DevModel& m) {
-    if constexpr (!GEN) {  // tail slope == 2*rs, b == 0: the CNS defaults
-        if constexpr (POT == 1) return 2.0f * fminf(delta, m.rs);
-        else if constexpr (POT == 0) return 2.0f * fminf(fmaxf(delta, -m.rs), m.rs);
-        else return 2.0f * delta;
-    } else {
-        const float ad = fabsf(delta);
-        const float tail = m.tail_c - m.tail_b / (ad * ad);
-        if constexpr (POT == 1) return delta > m.rs ? tail : 2.0f * delta;
-        else if constexpr (POT == 0) return ad > m.rs ? copysignf(tail, delta) : 2.0f * delta;
-        else return 2.0f * delta;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K2: forces on RPW consecutive rows, one wave, lanes across j.  The target row loads are
-// software-pipelined one j-block ahead (tv = block being computed, tn = block in flight); the
-// caller issues the first block before it stages xyz in LDS (tile_prefetch) so that their
-// L2 latency overlaps the staging.  On return lane l holds the force on row row0 + (l & (RPW-1)).
-// ---------------------------------------------------------------------------------------------
-// One "column block" = 256 columns: lane l owns columns 256*jb + 4l .. 4l+3, so every target
-// load is a 16-byte global_load_dwordx4 and every coordinate read a ds_read_b128 (dword loads
-// are address-rate bound in the texture path: 1 pair per load instruction-lane starves the VALU).
-template <int RPW>
-__device__ __forceinline__ void tile_prefetch(const DevModel& m, const float* __restrict__ tgt, int row0, int lane,
-                                              int jb, float4 (&tv)[RPW]) {
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-        tv[r] = *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 256 * jb + 4 * lane);
-}
-
-// One pair term.  F_i += c * (x_i - x_j) with c = -(dE/dd)/d.  Written to minimise VALU issue slots
-// (this is the inner loop of the whole solver):
-//   r2 carries a +1e-12 guard inside the fma chain (no separate max);
-//   NOE, CNS-default tail (slope 2 rs): with u = (d - t)/d = 1 - t/d the clamp of the soft-square acts on
-//   u directly: -(dE/dd)/d = -2 w S min(u, rs/d)  (d itself is never formed);
-//   repel: max(0, R2 - r2) = R2 * clamp01(1 - r2/R2) is ONE v_fma_f32 with the clamp output modifier.
-template <int POT, bool GEN>
-__device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, float v, float dx, float dy, float dz,
-                                          float& fx, float& fy, float& fz) {
-    const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, 1e-12f)));
-    const float rinv = __builtin_amdgcn_rsqf(r2);
-    float s;   // (dE/dd) / (2 d) without the weights
-    if constexpr (!GEN) {
-        const float u = fmaf(-v, rinv, 1.0f);          // (d - t) / d
-        const float lim = m.rs * rinv;                 // rs / d
-        if constexpr (POT == 1) s = fminf(u, lim);
-        else if constexpr (POT == 0) s = fminf(fmaxf(u, -lim), lim);
-        else s = u;
-    } else {
-        s = 0.5f * noe_grad<POT, GEN>(r2 * rinv - v, m) * rinv;
-    }
-    float c = (v > 0.0f) ? p.w_noe2n * s : 0.0f;      // v = target (A), 0 = no restraint; w_noe2n = -2 w S
-    // repel on EVERY column: padding beads are 1e4 A away (q = 0), the self term has dx = 0, and the
-    // |i-j| < rep_sep neighbours are taken back out in the chain-term pass below
-    float q01;   // clamp01(1 - r2/R2): the clamp is an output modifier of the fma (hipcc has no builtin for it)
-    asm("v_fma_f32 %0, -%1, %2, 1.0 clamp" : "=v"(q01) : "v"(r2), "v"(p.inv_rep_r2));
-    c = fmaf(p.w_rep4r2, q01, c);                      // 4 w_vdw k_rep R2 * clamp01(1 - r2/R2)
-    fx = fmaf(c, dx, fx);
-    fy = fmaf(c, dy, fy);
-    fz = fmaf(c, dz, fz);
-}
-
-template <int POT, bool GEN, int RPW>
-__device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p, const float* __restrict__ tgt,
-                                            const float* xs, const float* ys, const float* zs, int row0, int lane,
-                                            float4 (&tv)[RPW], float& Fx, float& Fy, float& Fz) {
-    float fx[RPW], fy[RPW], fz[RPW];
-    float xi[RPW], yi[RPW], zi[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int row = min(row0 + r, m.n - 1);
-        xi[r] = xs[row]; yi[r] = ys[row]; zi[r] = zs[row];
-        fx[r] = fy[r] = fz[r] = 0.0f;
-    }
-    const int nblk = m.npad >> 8;
-    for (int jb = 0; jb < nblk; ++jb) {
-        float4 tn[RPW];
-        const int jn = jb + 1 < nblk ? jb + 1 : jb;     // last block re-reads itself (in bounds)
-        tile_prefetch<RPW>(m, tgt, row0, lane, jn, tn);  // next block in flight while this one computes
-        const int j = 256 * jb + 4 * lane;
-        const float4 xj = *reinterpret_cast<const float4*>(xs + j);
-        const float4 yj = *reinterpret_cast<const float4*>(ys + j);
-        const float4 zj = *reinterpret_cast<const float4*>(zs + j);
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            pair_term<POT, GEN>(m, p, tv[r].x, xi[r] - xj.x, yi[r] - yj.x, zi[r] - zj.x, fx[r], fy[r], fz[r]);
-            pair_term<POT, GEN>(m, p, tv[r].y, xi[r] - xj.y, yi[r] - yj.y, zi[r] - zj.y, fx[r], fy[r], fz[r]);
-            pair_term<POT, GEN>(m, p, tv[r].z, xi[r] - xj.z, yi[r] - yj.z, zi[r] - zj.z, fx[r], fy[r], fz[r]);
-            pair_term<POT, GEN>(m, p, tv[r].w, xi[r] - xj.w, yi[r] - yj.w, zi[r] - zj.w, fx[r], fy[r], fz[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) tv[r] = tn[r];
-    }
-    // chain terms: pseudo-bond (i,i+-1), pseudo-angle (i,i+-2) and the repel take-back for
-    // |i-j| < rep_sep.  Lane l < 4*RPW handles neighbour (l & 3) of row (l >> 2) — one pass for all rows.
-    {
-        const int nb = lane & 3;
-        const int off = nb < 2 ? nb - 2 : nb - 1;          // -2,-1,+1,+2
-        const int sep = off < 0 ? -off : off;
-        const int rsel = lane >> 2;                          // row of this lane (valid while lane < 4*RPW)
-        const int row = min(row0 + rsel, m.n - 1);
-        const int jn = row + off;
-        float cx = 0.0f, cy = 0.0f, cz = 0.0f;
-        if (lane < 4 * RPW && row0 + rsel < m.n && jn >= 0 && jn < m.n) {
-            const float dx = xs[row] - xs[jn], dy = ys[row] - ys[jn], dz = zs[row] - zs[jn];
-            const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
-            const float rinv = __builtin_amdgcn_rsqf(r2);
-            const float d = r2 * rinv;
-            const float k2 = sep == 1 ? m.k_bond2 : m.k_ang2;
-            const float r0 = sep == 1 ? m.b0 : m.a0;
-            const bool on = sep == 1 || (m.k_ang2 > 0.0f && (m.ang_mode == 1 || d < m.a0));
-            float c = on ? -p.w_all * k2 * (d - r0) * rinv : 0.0f;
-            if (sep < m.rep_sep) c -= p.w_rep4 * fmaxf(p.rep_r2 - r2, 0.0f);
-            cx = c * dx; cy = c * dy; cz = c * dz;
-        }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const bool mine = rsel == r;
-            fx[r] += mine ? cx : 0.0f;
-            fy[r] += mine ? cy : 0.0f;
-            fz[r] += mine ? cz : 0.0f;
-        }
-    }
-    Fx = reduce_rows<RPW>(fx, lane);
-    Fy = reduce_rows<RPW>(fy, lane);
-    Fz = reduce_rows<RPW>(fz, lane);
-}
 
 // ---------------------------------------------------------------------------------------------
 // K3/K4: one SA step (MD leap-frog or FIRE) for all replicas.
@@ -253,20 +59,6 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
 //   3. pair loop with the target loads pipelined one block ahead
 //   4. lanes 0..RPW-1 finish one row each; tile partial sums through LDS
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 wave_sum4(float4 a) {
-    return make_float4(wave_sum(a.x), wave_sum(a.y), wave_sum(a.z), wave_sum(a.w));
-}
-
-// async global -> LDS copy of `count` floats (count % 256 == 0), 16 bytes per lane per instruction
-// (global_load_lds_dwordx4: LDS address = wave-uniform base + lane*16, no VGPR round trip).  The
-// caller's __syncthreads() waits for it (hipcc emits s_waitcnt vmcnt(0) before the barrier).
-template <int BLOCK>
-__device__ __forceinline__ void lds_dma_copy(const float* __restrict__ src, float* dst, int count, int tid) {
-    const int lane = tid & 63;
-    for (int b = 4 * tid; b < count; b += 4 * BLOCK)
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + b),
-                                         (void __attribute__((address_space(3)))*)(dst + (b - 4 * lane)), 16, 0, 0);
-}
 
 template <int POT, bool GEN, int RPW>
 __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
@@ -291,7 +83,6 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     const int row = row0 + (lane & (RPW - 1));  // the row this lane finishes (lanes < RPW only)
     const bool finisher = lane < RPW && row < m.n;
     const size_t ix = roff + row, iy = ix + npad, iz = iy + npad;
-    const bool is_md = p.kind == 0 || p.kind == 1 || p.kind == 4;
     const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
 
     // ---- 1. every independent global load is issued before anything waits -------------------
@@ -318,32 +109,9 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     C3D_STAMP(1);
 
     // ---- 2. scalars per wave (no barrier; every wave derives the same values) -----------------
-    float lam = 1.0f, cmx = 0.0f, cmy = 0.0f, cmz = 0.0f;   // MD
-    float keep = 0.0f, mix = 0.0f;                           // FIRE
     if (needs_partials) psum = wave_sum4(psum);
-    if (p.kind == 0 || p.kind == 1) {   // psum = (sum v^2, sum vx, sum vy, sum vz) of the previous half step
-        const float tprev = fmaxf(m.t_fac * psum.x, 1e-2f);
-        if (p.kind == 0) lam = sqrtf(fmaxf(1.0f + p.dt * m.fbeta * (p.t_bath / tprev - 1.0f), 0.0f));
-        else lam = sqrtf(p.t_bath / tprev);
-        cmx = psum.y * m.inv_n; cmy = psum.z * m.inv_n; cmz = psum.w * m.inv_n;
-    } else if (p.kind == 2 || p.kind == 3) {
-        // FIRE (Bitzek et al. 2006) with the power test on the previous step's sums
-        // psum = (v.F, F.F, v.v); kind 3 = first step of a stage: psum = 0, fresh state
-        if (psum.x > 0.0f) {
-            keep = 1.0f - st.alpha;
-            mix = st.alpha * sqrtf(psum.z / fmaxf(psum.y, 1e-30f));
-            if (st.npos > fp.n_min) {
-                st.dt = fminf(st.dt * fp.f_inc, fp.dt_max);
-                st.alpha *= fp.f_alpha;
-            }
-            st.npos += 1;
-        } else {
-            st.alpha = fp.alpha_start;
-            st.dt *= fp.f_dec;
-            st.npos = 0;
-        }
-        if (tile == 0 && tid == 0) sout[rep] = st;
-    }
+    const StepScalars sc = step_scalars(m, p, fp, psum, st);
+    if ((p.kind == 2 || p.kind == 3) && tile == 0 && tid == 0) sout[rep] = st;
     C3D_STAMP(2);
     __syncthreads();
     C3D_STAMP(3);
@@ -357,32 +125,7 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     float4 q = make_float4(0, 0, 0, 0);   // this lane's contribution to the tile's partial sums
     if (finisher) {
         float vx, vy, vz, xn, yn, zn;
-        if (is_md) {
-            if (p.kind == 4) {            // MD begin: take the Maxwell velocities, no move
-                vx = vx0; vy = vy0; vz = vz0;
-                xn = xs[row]; yn = ys[row]; zn = zs[row];
-            } else {
-                const float a = p.dt * m.acc;
-                vx = fmaf(a, Fx, lam * (vx0 - cmx));
-                vy = fmaf(a, Fy, lam * (vy0 - cmy));
-                vz = fmaf(a, Fz, lam * (vz0 - cmz));
-                xn = fmaf(p.dt, vx, xs[row]);
-                yn = fmaf(p.dt, vy, ys[row]);
-                zn = fmaf(p.dt, vz, zs[row]);
-            }
-            q = make_float4(vx * vx + vy * vy + vz * vz, vx, vy, vz);
-        } else {
-            // sums of THIS evaluation for the next step's test, with the velocity that led here
-            q = make_float4(vx0 * Fx + vy0 * Fy + vz0 * Fz, Fx * Fx + Fy * Fy + Fz * Fz, vx0 * vx0 + vy0 * vy0 + vz0 * vz0, 0.0f);
-            const float a = st.dt * m.acc;
-            vx = fmaf(a, Fx, keep * vx0 + mix * Fx);
-            vy = fmaf(a, Fy, keep * vy0 + mix * Fy);
-            vz = fmaf(a, Fz, keep * vz0 + mix * Fz);
-            const float dxs = st.dt * vx, dys = st.dt * vy, dzs = st.dt * vz;
-            const float d2 = dxs * dxs + dys * dys + dzs * dzs;
-            const float sc = d2 > fp.max_step * fp.max_step ? fp.max_step * __builtin_amdgcn_rsqf(d2) : 1.0f;
-            xn = fmaf(sc, dxs, xs[row]); yn = fmaf(sc, dys, ys[row]); zn = fmaf(sc, dzs, zs[row]);
-        }
+        finish_row(m, p, fp, sc, st, Fx, Fy, Fz, xs[row], ys[row], zs[row], vx0, vy0, vz0, xn, yn, zn, vx, vy, vz, q);
         xout[ix] = xn; xout[iy] = yn; xout[iz] = zn;
         vout[ix] = vx; vout[iy] = vy; vout[iz] = vz;
     }

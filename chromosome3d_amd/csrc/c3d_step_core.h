@@ -1,0 +1,342 @@
+// c3d_step_core.h — device-side building blocks of one SA step, shared by the per-step kernel
+// (k_step, c3d_device.hip) and the resident multi-step kernel (k_anneal, c3d_resident.hip).  Both kernels
+// run exactly these functions in the same order, so their trajectories are bit-identical.
+#pragma once
+#include "c3d_internal.h"
+
+// Every fused multiply-add in this file is written as fmaf(): with implicit contraction the compiler picks
+// which product of a*b + c*d to fuse from the surrounding code, and the two kernels would drift apart.
+#pragma clang fp contract(off)
+
+namespace c3d {
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+// Wave64 reductions on the VALU only (no ds_bpermute / LDS crossbar round trips):
+//   lanes ^1, ^2      v_add_f32_dpp quad_perm
+//   lanes -4, -8      v_add_f32_dpp row_ror:4 / row_ror:8   (sum of the 16-lane row, position kept)
+//   rows ^1, halves   v_permlane16_swap / v_permlane32_swap  (gfx950) + v_add
+// gfx9 DPP controls: quad_perm[a,b,c,d] = a|b<<2|c<<4|d<<6, row_ror:n = 0x120+n.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float xrow_sum(float v) {   // + the other three 16-lane rows, every lane
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float wave_sum(float v) {   // total in every lane
+    v += dpp_mov<0xB1>(v);          // lanes ^1
+    v += dpp_mov<0x4E>(v);          // lanes ^2
+    v += dpp_mov<0x124>(v);         // row_ror:4
+    v += dpp_mov<0x128>(v);         // row_ror:8
+    return xrow_sum(v);
+}
+// sum over the low RPW lanes of each quad (RPW in {1,2,4}); valid in lane 0
+template <int RPW>
+__device__ __forceinline__ float quad_sum(float v) {
+    if constexpr (RPW >= 2) v += dpp_mov<0xB1>(v);
+    if constexpr (RPW >= 4) v += dpp_mov<0x4E>(v);
+    return v;
+}
+// Transposing reduction: a[r] is this lane's partial sum for row r.  Returns, in every lane l, the
+// sum over all 64 lanes of a[l & (RPW-1)]: the row selection rides on the first butterfly levels
+// (lane parity picks which row a lane keeps), every later level preserves lane & 3.
+template <int RPW>
+__device__ __forceinline__ float reduce_rows(const float (&a)[RPW], int lane) {
+    static_assert(RPW == 1 || RPW == 2 || RPW == 4, "rows per wave must be 1, 2 or 4");
+    float k;
+    if constexpr (RPW == 1) {
+        k = a[0];
+        k += dpp_mov<0xB1>(k);
+        k += dpp_mov<0x4E>(k);
+    } else if constexpr (RPW == 2) {
+        const bool b0 = lane & 1;
+        k = b0 ? a[1] : a[0];
+        const float s = b0 ? a[0] : a[1];
+        k += dpp_mov<0xB1>(s);
+        k += dpp_mov<0x4E>(k);
+    } else {
+        const bool b0 = lane & 1, b1 = lane & 2;
+        float k01 = b0 ? a[1] : a[0];
+        const float s01 = b0 ? a[0] : a[1];
+        float k23 = b0 ? a[3] : a[2];
+        const float s23 = b0 ? a[2] : a[3];
+        k01 += dpp_mov<0xB1>(s01);
+        k23 += dpp_mov<0xB1>(s23);
+        k = b1 ? k23 : k01;
+        const float s = b1 ? k01 : k23;
+        k += dpp_mov<0x4E>(s);
+    }
+    k += dpp_mov<0x124>(k);
+    k += dpp_mov<0x128>(k);
+    return xrow_sum(k);
+}
+
+template <int POT, bool GEN>
+__device__ __forceinline__ float noe_grad(float delta, const DevModel& m) {
+    if constexpr (!GEN) {  // tail slope == 2*rs, b == 0: the CNS defaults
+        if constexpr (POT == 1) return 2.0f * fminf(delta, m.rs);
+        else if constexpr (POT == 0) return 2.0f * fminf(fmaxf(delta, -m.rs), m.rs);
+        else return 2.0f * delta;
+    } else {
+        const float ad = fabsf(delta);
+        const float tail = m.tail_c - m.tail_b / (ad * ad);
+        if constexpr (POT == 1) return delta > m.rs ? tail : 2.0f * delta;
+        else if constexpr (POT == 0) return ad > m.rs ? copysignf(tail, delta) : 2.0f * delta;
+        else return 2.0f * delta;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: forces on RPW consecutive rows, one wave, lanes across j.  The target row loads are
+// software-pipelined one j-block ahead (tv = block being computed, tn = block in flight); the
+// caller issues the first block before it stages xyz in LDS (tile_prefetch) so that their
+// L2 latency overlaps the staging.  On return lane l holds the force on row row0 + (l & (RPW-1)).
+// ---------------------------------------------------------------------------------------------
+// One "column block" = 256 columns: lane l owns columns 256*jb + 4l .. 4l+3, so every target
+// load is a 16-byte global_load_dwordx4 and every coordinate read a ds_read_b128 (dword loads
+// are address-rate bound in the texture path: 1 pair per load instruction-lane starves the VALU).
+template <int RPW>
+__device__ __forceinline__ void tile_prefetch(const DevModel& m, const float* __restrict__ tgt, int row0, int lane,
+                                              int jb, float4 (&tv)[RPW]) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+        tv[r] = *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 256 * jb + 4 * lane);
+}
+
+// One pair term.  F_i += c * (x_i - x_j) with c = -(dE/dd)/d.  Written to minimise VALU issue slots
+// (this is the inner loop of the whole solver):
+//   r2 carries a +1e-12 guard inside the fma chain (no separate max);
+//   NOE, CNS-default tail (slope 2 rs): with u = (d - t)/d = 1 - t/d the clamp of the soft-square acts on
+//   u directly: -(dE/dd)/d = -2 w S min(u, rs/d)  (d itself is never formed);
+//   repel: max(0, R2 - r2) = R2 * clamp01(1 - r2/R2) is ONE v_fma_f32 with the clamp output modifier.
+template <int POT, bool GEN>
+__device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, float v, float dx, float dy, float dz,
+                                          float& fx, float& fy, float& fz) {
+    const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, 1e-12f)));
+    const float rinv = __builtin_amdgcn_rsqf(r2);
+    float s;   // (dE/dd) / (2 d) without the weights
+    if constexpr (!GEN) {
+        const float u = fmaf(-v, rinv, 1.0f);          // (d - t) / d
+        const float lim = m.rs * rinv;                 // rs / d
+        if constexpr (POT == 1) s = fminf(u, lim);
+        else if constexpr (POT == 0) s = fminf(fmaxf(u, -lim), lim);
+        else s = u;
+    } else {
+        s = 0.5f * noe_grad<POT, GEN>(r2 * rinv - v, m) * rinv;
+    }
+    float c = (v > 0.0f) ? p.w_noe2n * s : 0.0f;      // v = target (A), 0 = no restraint; w_noe2n = -2 w S
+    // repel on EVERY column: padding beads are 1e4 A away (q = 0), the self term has dx = 0, and the
+    // |i-j| < rep_sep neighbours are taken back out in the chain-term pass below
+    float q01;   // clamp01(1 - r2/R2): the clamp is an output modifier of the fma (hipcc has no builtin for it)
+    asm("v_fma_f32 %0, -%1, %2, 1.0 clamp" : "=v"(q01) : "v"(r2), "v"(p.inv_rep_r2));
+    c = fmaf(p.w_rep4r2, q01, c);                      // 4 w_vdw k_rep R2 * clamp01(1 - r2/R2)
+    fx = fmaf(c, dx, fx);
+    fy = fmaf(c, dy, fy);
+    fz = fmaf(c, dz, fz);
+}
+
+// the four pair terms of one lane and one row against columns j .. j+3 (targets tv)
+template <int POT, bool GEN>
+__device__ __forceinline__ void pair_quad(const DevModel& m, const DevStep& p, const float4 tv, float xi, float yi, float zi,
+                                          const float4 xj, const float4 yj, const float4 zj, float& fx, float& fy, float& fz) {
+    pair_term<POT, GEN>(m, p, tv.x, xi - xj.x, yi - yj.x, zi - zj.x, fx, fy, fz);
+    pair_term<POT, GEN>(m, p, tv.y, xi - xj.y, yi - yj.y, zi - zj.y, fx, fy, fz);
+    pair_term<POT, GEN>(m, p, tv.z, xi - xj.z, yi - yj.z, zi - zj.z, fx, fy, fz);
+    pair_term<POT, GEN>(m, p, tv.w, xi - xj.w, yi - yj.w, zi - zj.w, fx, fy, fz);
+}
+
+// chain terms: pseudo-bond (i,i+-1), pseudo-angle (i,i+-2) and the repel take-back for |i-j| < rep_sep.
+// Lane l < 4*RPW handles neighbour (l & 3) of row (l >> 2) — one pass for all rows; then the transposing
+// reduction that leaves the force on row row0 + (l & (RPW-1)) in lane l.
+template <int RPW>
+__device__ __forceinline__ void chain_and_reduce(const DevModel& m, const DevStep& p, const float* xs, const float* ys,
+                                                 const float* zs, int row0, int lane, float (&fx)[RPW], float (&fy)[RPW],
+                                                 float (&fz)[RPW], float& Fx, float& Fy, float& Fz) {
+    const int nb = lane & 3;
+    const int off = nb < 2 ? nb - 2 : nb - 1;          // -2,-1,+1,+2
+    const int sep = off < 0 ? -off : off;
+    const int rsel = lane >> 2;                          // row of this lane (valid while lane < 4*RPW)
+    const int row = min(row0 + rsel, m.n - 1);
+    const int jn = row + off;
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+    if (lane < 4 * RPW && row0 + rsel < m.n && jn >= 0 && jn < m.n) {
+        const float dx = xs[row] - xs[jn], dy = ys[row] - ys[jn], dz = zs[row] - zs[jn];
+        const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
+        const float rinv = __builtin_amdgcn_rsqf(r2);
+        const float d = r2 * rinv;
+        const float k2 = sep == 1 ? m.k_bond2 : m.k_ang2;
+        const float r0 = sep == 1 ? m.b0 : m.a0;
+        const bool on = sep == 1 || (m.k_ang2 > 0.0f && (m.ang_mode == 1 || d < m.a0));
+        float c = on ? -p.w_all * k2 * (d - r0) * rinv : 0.0f;
+        if (sep < m.rep_sep) c = fmaf(-p.w_rep4, fmaxf(p.rep_r2 - r2, 0.0f), c);
+        cx = c * dx; cy = c * dy; cz = c * dz;
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const bool mine = rsel == r;
+        fx[r] += mine ? cx : 0.0f;
+        fy[r] += mine ? cy : 0.0f;
+        fz[r] += mine ? cz : 0.0f;
+    }
+    Fx = reduce_rows<RPW>(fx, lane);
+    Fy = reduce_rows<RPW>(fy, lane);
+    Fz = reduce_rows<RPW>(fz, lane);
+}
+
+// targets streamed from global memory, one column block ahead (per-step kernel)
+template <int POT, bool GEN, int RPW>
+__device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p, const float* __restrict__ tgt,
+                                            const float* xs, const float* ys, const float* zs, int row0, int lane,
+                                            float4 (&tv)[RPW], float& Fx, float& Fy, float& Fz) {
+    float fx[RPW], fy[RPW], fz[RPW];
+    float xi[RPW], yi[RPW], zi[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, m.n - 1);
+        xi[r] = xs[row]; yi[r] = ys[row]; zi[r] = zs[row];
+        fx[r] = fy[r] = fz[r] = 0.0f;
+    }
+    const int nblk = m.npad >> 8;
+    for (int jb = 0; jb < nblk; ++jb) {
+        float4 tn[RPW];
+        const int jn = jb + 1 < nblk ? jb + 1 : jb;     // last block re-reads itself (in bounds)
+        tile_prefetch<RPW>(m, tgt, row0, lane, jn, tn);  // next block in flight while this one computes
+        const int j = 256 * jb + 4 * lane;
+        const float4 xj = *reinterpret_cast<const float4*>(xs + j);
+        const float4 yj = *reinterpret_cast<const float4*>(ys + j);
+        const float4 zj = *reinterpret_cast<const float4*>(zs + j);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) pair_quad<POT, GEN>(m, p, tv[r], xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) tv[r] = tn[r];
+    }
+    chain_and_reduce<RPW>(m, p, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
+}
+
+// targets resident in registers for the whole launch (resident kernel): NB column blocks, fully unrolled
+template <int POT, bool GEN, int RPW, int NB>
+__device__ __forceinline__ void tile_forces_reg(const DevModel& m, const DevStep& p, const float4 (&tv)[RPW][NB],
+                                                const float* xs, const float* ys, const float* zs, int row0, int lane,
+                                                float& Fx, float& Fy, float& Fz) {
+    float fx[RPW], fy[RPW], fz[RPW];
+    float xi[RPW], yi[RPW], zi[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, m.n - 1);
+        xi[r] = xs[row]; yi[r] = ys[row]; zi[r] = zs[row];
+        fx[r] = fy[r] = fz[r] = 0.0f;
+    }
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+        const int j = 256 * jb + 4 * lane;
+        const float4 xj = *reinterpret_cast<const float4*>(xs + j);
+        const float4 yj = *reinterpret_cast<const float4*>(ys + j);
+        const float4 zj = *reinterpret_cast<const float4*>(zs + j);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            pair_quad<POT, GEN>(m, p, tv[r][jb], xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+            // four pair terms in flight, not 4 * RPW * NB: this row's sums must exist before the next row's
+            // coordinates may be used (the resident launch needs 5 waves per SIMD, i.e. <= 96 VGPRs)
+            const int rn = (r + 1) % RPW;
+            asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]), "+v"(xi[rn]), "+v"(yi[rn]), "+v"(zi[rn]));
+        }
+    }
+    chain_and_reduce<RPW>(m, p, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-replica scalars of a step from the previous step's sums, identical in every wave
+// ---------------------------------------------------------------------------------------------
+struct StepScalars {
+    float lam, cmx, cmy, cmz;   // MD: velocity scale, centre-of-mass velocity
+    float keep, mix;            // FIRE: velocity mixing
+};
+// psum: MD kinds 0/1 = (sum v^2, sum vx, sum vy, sum vz) of the previous half step;
+//       FIRE kind 2 = (v.F, F.F, v.v) of the previous evaluation; kind 3 (first step of a stage) = 0, fresh state
+__device__ __forceinline__ StepScalars step_scalars(const DevModel& m, const DevStep& p, const DevFire& fp, const float4 psum,
+                                                    FireState& st) {
+    StepScalars s;
+    s.lam = 1.0f; s.cmx = s.cmy = s.cmz = 0.0f; s.keep = 0.0f; s.mix = 0.0f;
+    if (p.kind == 0 || p.kind == 1) {
+        const float tprev = fmaxf(m.t_fac * psum.x, 1e-2f);
+        if (p.kind == 0) s.lam = sqrtf(fmaxf(fmaf(p.dt * m.fbeta, p.t_bath / tprev - 1.0f, 1.0f), 0.0f));
+        else s.lam = sqrtf(p.t_bath / tprev);
+        s.cmx = psum.y * m.inv_n; s.cmy = psum.z * m.inv_n; s.cmz = psum.w * m.inv_n;
+    } else if (p.kind == 2 || p.kind == 3) {
+        // FIRE (Bitzek et al. 2006) with the power test on the previous step's sums
+        if (psum.x > 0.0f) {
+            s.keep = 1.0f - st.alpha;
+            s.mix = st.alpha * sqrtf(psum.z / fmaxf(psum.y, 1e-30f));
+            if (st.npos > fp.n_min) {
+                st.dt = fminf(st.dt * fp.f_inc, fp.dt_max);
+                st.alpha *= fp.f_alpha;
+            }
+            st.npos += 1;
+        } else {
+            st.alpha = fp.alpha_start;
+            st.dt *= fp.f_dec;
+            st.npos = 0;
+        }
+    }
+    return s;
+}
+
+// one row's update from its force: new position, new velocity and the row's contribution q to the
+// replica sums the NEXT step needs
+__device__ __forceinline__ void finish_row(const DevModel& m, const DevStep& p, const DevFire& fp, const StepScalars& sc,
+                                           const FireState& st, float Fx, float Fy, float Fz, float x0, float y0, float z0,
+                                           float vx0, float vy0, float vz0, float& xn, float& yn, float& zn, float& vx,
+                                           float& vy, float& vz, float4& q) {
+    const bool is_md = p.kind == 0 || p.kind == 1 || p.kind == 4;
+    if (is_md) {
+        if (p.kind == 4) {            // MD begin: take the Maxwell velocities, no move
+            vx = vx0; vy = vy0; vz = vz0;
+            xn = x0; yn = y0; zn = z0;
+        } else {
+            const float a = p.dt * m.acc;
+            vx = fmaf(a, Fx, sc.lam * (vx0 - sc.cmx));
+            vy = fmaf(a, Fy, sc.lam * (vy0 - sc.cmy));
+            vz = fmaf(a, Fz, sc.lam * (vz0 - sc.cmz));
+            xn = fmaf(p.dt, vx, x0);
+            yn = fmaf(p.dt, vy, y0);
+            zn = fmaf(p.dt, vz, z0);
+        }
+        q = make_float4(fmaf(vx, vx, fmaf(vy, vy, vz * vz)), vx, vy, vz);
+    } else {
+        // sums of THIS evaluation for the next step's test, with the velocity that led here
+        q = make_float4(fmaf(vx0, Fx, fmaf(vy0, Fy, vz0 * Fz)), fmaf(Fx, Fx, fmaf(Fy, Fy, Fz * Fz)),
+                        fmaf(vx0, vx0, fmaf(vy0, vy0, vz0 * vz0)), 0.0f);
+        const float a = st.dt * m.acc;
+        vx = fmaf(a, Fx, fmaf(sc.keep, vx0, sc.mix * Fx));
+        vy = fmaf(a, Fy, fmaf(sc.keep, vy0, sc.mix * Fy));
+        vz = fmaf(a, Fz, fmaf(sc.keep, vz0, sc.mix * Fz));
+        const float dxs = st.dt * vx, dys = st.dt * vy, dzs = st.dt * vz;
+        const float d2 = fmaf(dxs, dxs, fmaf(dys, dys, dzs * dzs));
+        const float scl = d2 > fp.max_step * fp.max_step ? fp.max_step * __builtin_amdgcn_rsqf(d2) : 1.0f;
+        xn = fmaf(scl, dxs, x0); yn = fmaf(scl, dys, y0); zn = fmaf(scl, dzs, z0);
+    }
+}
+
+__device__ __forceinline__ float4 wave_sum4(float4 a) {
+    return make_float4(wave_sum(a.x), wave_sum(a.y), wave_sum(a.z), wave_sum(a.w));
+}
+
+// async global -> LDS copy of `count` floats (count % 256 == 0), 16 bytes per lane per instruction
+// (global_load_lds_dwordx4: LDS address = wave-uniform base + lane*16, no VGPR round trip).  The
+// caller's __syncthreads() waits for it (hipcc emits s_waitcnt vmcnt(0) before the barrier).
+template <int BLOCK>
+__device__ __forceinline__ void lds_dma_copy(const float* __restrict__ src, float* dst, int count, int tid) {
+    const int lane = tid & 63;
+    for (int b = 4 * tid; b < count; b += 4 * BLOCK)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + b),
+                                         (void __attribute__((address_space(3)))*)(dst + (b - 4 * lane)), 16, 0, 0);
+}
+
+}  // namespace c3d
+
+#pragma clang fp contract(fast)
