@@ -114,8 +114,8 @@ struct c3d_ctx {
 
     // resident kernel state: device copy of the program's step parameters, the two pointer blocks (by
     // parity), the tile-record hand-off area and the timeout word
-    c3d::DevStep* d_program = nullptr;
-    bool program_uploaded = false;
+    c3d::StepRun* d_runs = nullptr;        // run-length coded step parameters of the launch in flight
+    size_t runs_cap = 0;
     c3d::AnnealIO* d_io = nullptr;         // [2]
     void* d_rec = nullptr;
     size_t rec_bytes = 0;
@@ -213,7 +213,6 @@ void build_program(c3d_ctx* c) {
         prev_kind = st.kind;
     }
     c->pc = 0;
-    c->program_uploaded = false;
     c->resident_cap = -1;
     drop_graphs(c);
 }
@@ -284,18 +283,24 @@ bool resident_ok(c3d_ctx* c) {
 }
 
 int run_resident(c3d_ctx* c, size_t nops) {
-    if (!c->program_uploaded) {
-        if (c->d_program) { hipFree(c->d_program); c->d_program = nullptr; }
-        std::vector<c3d::DevStep> h(c->program.size());
-        for (size_t k = 0; k < h.size(); ++k) h[k] = c->program[k].p;
-        HIP_TRY(hipMalloc(&c->d_program, sizeof(c3d::DevStep) * h.size()));
-        HIP_TRY(hipMemcpy(c->d_program, h.data(), sizeof(c3d::DevStep) * h.size(), hipMemcpyHostToDevice));
-        c->program_uploaded = true;
+    // consecutive ops with identical parameters become one run (a FIRE stage is 2 runs, the cool ramp 81)
+    std::vector<c3d::StepRun> runs;
+    for (size_t k = 0; k < nops; ++k) {
+        const c3d::DevStep& p = c->program[c->pc + k].p;
+        if (!runs.empty() && memcmp(&runs.back().p, &p, sizeof(p)) == 0) ++runs.back().count;
+        else runs.push_back({p, 1});
     }
+    if (runs.size() > c->runs_cap) {
+        if (c->d_runs) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_runs); c->d_runs = nullptr; }
+        c->runs_cap = std::max<size_t>(runs.size(), 256);
+        HIP_TRY(hipMalloc(&c->d_runs, sizeof(c3d::StepRun) * c->runs_cap));
+    }
+    // stream-ordered after the previous launch (pageable source: the call returns once the data is staged)
+    HIP_TRY(hipMemcpyAsync(c->d_runs, runs.data(), sizeof(c3d::StepRun) * runs.size(), hipMemcpyHostToDevice, c->stream));
     const c3d::DevModel m = dev_model(c);
     HIP_TRY(hipMemsetAsync(c->d_rec, 0, c->rec_bytes, c->stream));
     hipError_t e = c3d::launch_anneal(m, dev_fire(c), c->d_io + c->parity, c->buf.tgt, general_tail(m), c->d_rec,
-                                      c->d_program + c->pc, (int)nops, c->d_tmo, c->stream);
+                                      c->d_runs, (int)runs.size(), (int)nops, c->d_tmo, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("resident launch: ") + hipGetErrorString(e));
     c->resident_pending = true;
     c->parity ^= 1;
@@ -516,7 +521,7 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
     drop_graphs(c);
     free_replica_buffers(c);
     if (c->buf.tgt) hipFree(c->buf.tgt);
-    if (c->d_program) hipFree(c->d_program);
+    if (c->d_runs) hipFree(c->d_runs);
     if (c->d_tmo) hipFree(c->d_tmo);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -967,7 +972,11 @@ extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
 }
 
 #ifdef C3D_STAMPS
-namespace c3d { hipError_t read_stamps(unsigned long long* out); }
+namespace c3d { hipError_t read_stamps(unsigned long long* out); hipError_t read_resident_stamps(unsigned long long* out); }
+extern "C" int c3d_debug_resident_stamps(unsigned long long* out) {
+    hipError_t e = c3d::read_resident_stamps(out);
+    return e == hipSuccess ? C3D_OK : C3D_ERR_HIP;
+}
 extern "C" int c3d_debug_stamps(unsigned long long* out) {
     hipError_t e = c3d::read_stamps(out);
     return e == hipSuccess ? C3D_OK : C3D_ERR_HIP;

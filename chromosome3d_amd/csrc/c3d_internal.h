@@ -79,11 +79,15 @@ hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuff
 hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe,
                          float k_rep, hipStream_t s);
 hipError_t launch_centre(const DevModel& m, const DevBuffers& b, int parity, hipStream_t s);
-// resident multi-step kernel (c3d_resident.hip): steps[0..nsteps) in ONE launch for every replica; reads parity
+// resident multi-step kernel (c3d_resident.hip): the steps of runs[0..nruns) (nsteps in all) in ONE launch for every replica; reads parity
 // `parity`, writes parity^1 once at the end.  rec = anneal_record_bytes() of zeroed device memory, *timeout = 0.
 bool anneal_supported(const DevModel& m);
 size_t anneal_record_bytes(const DevModel& m);
 hipError_t anneal_blocks_per_cu(const DevModel& m, bool general_tail, int* blocks_per_cu);
+struct StepRun {    // `count` consecutive steps with the same parameters
+    DevStep p;
+    int count;
+};
 struct AnnealIO {   // state buffers of one launch, in device memory (io = anneal_io(buffers, parity) uploaded by the host)
     const float *pin, *xin, *vin, *vinit;
     const FireState* sin;
@@ -92,7 +96,7 @@ struct AnnealIO {   // state buffers of one launch, in device memory (io = annea
 };
 AnnealIO anneal_io(const DevBuffers& b, int parity);
 hipError_t launch_anneal(const DevModel& m, const DevFire& fp, const AnnealIO* io, const float* tgt, bool general_tail, void* rec,
-                         const DevStep* steps, int nsteps, unsigned* timeout, hipStream_t s);
+                         const StepRun* runs, int nruns, int nsteps, unsigned* timeout, hipStream_t s);
 // K1: IF (n*n fp64, device) -> dist10 (n*n int32, device) and encoded targets (n*npad, device)
 hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, double K, int min_sep, int rep_sep,
                                double* scratchP, double* partial, int npartial, int32_t* dist10, float* tgt,

@@ -27,6 +27,22 @@ constexpr int kRecUnits = 16;                 // 16-byte units per tile record
 constexpr int kRecValues = 2 * kRecUnits;     // x[8] y[8] z[8] partial[4] pad[4]
 static_assert(kTileRows == 8, "record layout assumes 8 rows per tile");
 
+// Diagnostic build only (-DC3D_STAMPS, tools/stamps): cycles per phase of workgroup 0, summed over the steps of
+// a launch by its thread 0 (s_memtime), plus the number of gather sweeps.
+#ifdef C3D_STAMPS
+__device__ unsigned long long g_rstamps[16];
+#define RSTAMP(k)                                                                                       \
+    do {                                                                                                \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                      \
+            const unsigned long long t_ = __builtin_readcyclecounter();                                 \
+            racc[k] += t_ - rlast[0];                                                                   \
+            rlast[0] = t_;                                                                              \
+        }                                                                                               \
+    } while (0)
+#else
+#define RSTAMP(k) do { } while (0)
+#endif
+
 // Five waves per SIMD (20 replicas x 57 tiles x 4 waves on 1024 SIMDs) means <= 96 VGPRs and no SGPR to waste:
 // the ten state pointers are read from `io` where they are needed (start / end of the launch), not held in
 // registers across the step loop.
@@ -39,7 +55,8 @@ __device__ __forceinline__ const AnnealIO* late_pointers(const AnnealIO* io) {
 template <int POT, bool GEN, int NB>
 __global__ __launch_bounds__(256, 5) void k_anneal(
     const AnnealIO* __restrict__ io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
-    const DevStep* __restrict__ steps, const int nsteps, unsigned* __restrict__ timeout, const DevModel m, const DevFire fp) {
+    const StepRun* __restrict__ runs, const int nruns, const int nsteps, unsigned* __restrict__ timeout, const DevModel m,
+    const DevFire fp) {
     constexpr int RPW = 2, WAVES = kTileRows / RPW, BLOCK = 64 * WAVES;
     constexpr int NPAD = 256 * NB;
     constexpr int MAXT = NPAD / kTileRows;    // most tiles a replica can have at this NB
@@ -51,6 +68,11 @@ __global__ __launch_bounds__(256, 5) void k_anneal(
     float* ps = smem + 3 * NPAD;              // [MAXT][4] per-tile sums of the previous step
     float* stage = ps + 4 * MAXT;             // [32] this tile's record under construction
     float* wpart = stage + kRecValues;        // [WAVES][4]
+#ifdef C3D_STAMPS
+    unsigned long long* racc = reinterpret_cast<unsigned long long*>(wpart + 4 * WAVES + 4);   // [10]
+    unsigned long long* rlast = racc + 10;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { for (int k = 0; k < 10; ++k) racc[k] = 0; rlast[0] = __builtin_readcyclecounter(); }
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rep = blockIdx.x % m.nrep, tile = blockIdx.x / m.nrep;
     const size_t roff = (size_t)rep * 3 * NPAD;
@@ -80,14 +102,24 @@ __global__ __launch_bounds__(256, 5) void k_anneal(
         if (finisher) { vcx = vin[ix]; vcy = vin[iy]; vcz = vin[iz]; }
         st = io->sin[rep];
     }
-    DevStep pn = steps[0];
+    // gather bookkeeping of this thread: unit u = tid + 256 k holds values (2 qd, 2 qd + 1) of record u / 16
+    const int ulast = units - 1;
+    const int qd = tid & (kRecUnits - 1), cat = qd >> 2, within = (qd & 3) * 2;
+    float* const dump = wpart + 4 * WAVES;                              // 2 floats nobody reads
+    float* const dst0 = cat < 3 ? smem + cat * NPAD + (tid >> 4) * kTileRows + within
+                                : (qd < 14 ? ps + (tid >> 4) * 4 + within : dump);
+    const int dstride = cat < 3 ? (BLOCK / kRecUnits) * kTileRows : (qd < 14 ? (BLOCK / kRecUnits) * 4 : 0);
 
-    for (int s = 0; s < nsteps; ++s) {
-        const DevStep p = pn;
-        if (s + 1 < nsteps) pn = steps[s + 1];
-        const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
+    int s = 0;
+    for (int run = 0; run < nruns; ++run) {
+      const DevStep p = runs[run].p;
+      const int count = runs[run].count;
+      const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
+      for (int it = 0; it < count; ++it, ++s) {
         if (p.kind != 2) { st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0; }
+        RSTAMP(0);                                  // LDS writes of the gather / loop bookkeeping
         __syncthreads();                            // xs/ys/zs/ps of this step are in LDS
+        RSTAMP(1);                                  // barrier wait
 
         // ---- scalars per wave -----------------------------------------------------------------
         float4 psum = make_float4(0, 0, 0, 0);
@@ -99,11 +131,13 @@ __global__ __launch_bounds__(256, 5) void k_anneal(
             psum = wave_sum4(psum);
         }
         const StepScalars sc = step_scalars(m, p, fp, psum, st);
+        RSTAMP(2);                                  // sums + scalars
 
         // ---- K2 -------------------------------------------------------------------------------
         float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
         if (p.kind != 4) tile_forces_reg<POT, GEN, RPW, NB>(m, p, tv, xs, ys, zs, row0, lane, Fx, Fy, Fz);
 
+        RSTAMP(3);                                  // pair loop + reductions
         // ---- epilogue: lanes 0..RPW-1 finish one row each ---------------------------------------
         float4 q = make_float4(0, 0, 0, 0);
         float xn = 0.0f, yn = 0.0f, zn = 0.0f;
@@ -121,58 +155,68 @@ __global__ __launch_bounds__(256, 5) void k_anneal(
         }
         q.x = quad_sum<RPW>(q.x); q.y = quad_sum<RPW>(q.y); q.z = quad_sum<RPW>(q.z); q.w = quad_sum<RPW>(q.w);
         if (lane == 0) reinterpret_cast<float4*>(wpart)[wave] = q;
+        RSTAMP(4);                                  // row update
         __syncthreads();                            // all LDS reads of this step are done
-        float4 tsum = make_float4(0, 0, 0, 0);     // tile sums, fixed order over the waves
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const float4 u = reinterpret_cast<float4*>(wpart)[w];
-            tsum.x += u.x; tsum.y += u.y; tsum.z += u.z; tsum.w += u.w;
-        }
+        RSTAMP(5);                                  // barrier wait
+        const bool last = s + 1 == nsteps;
+        const unsigned tag = (unsigned)s + 1u;
+        const int base = (((s + 1) & 1) * m.nrep + rep) * units;
 
-        if (s + 1 == nsteps) {                      // hand the state back to the ordinary buffers
-            const AnnealIO* o = late_pointers(io);
-            float* xout = o->xout;
-            float* vout = o->vout;
-            float* pout = o->pout;
-            FireState* sout = o->sout;
+        // ---- wave 0: tile sums (fixed order over the waves), then publish the record or hand the state back
+        if (wave == 0) {
+            float4 tsum = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const float4 u = reinterpret_cast<float4*>(wpart)[w];
+                tsum.x += u.x; tsum.y += u.y; tsum.z += u.z; tsum.w += u.w;
+            }
+            if (last) {
+                if (tid == 0) {
+                    const AnnealIO* o = late_pointers(io);
+                    reinterpret_cast<float4*>(o->pout)[(size_t)rep * m.ntiles + tile] = tsum;
+                    if (tile == 0) o->sout[rep] = st;
+                }
+            } else if (lane < kRecUnits) {
+                const float2 sv = *reinterpret_cast<const float2*>(stage + 2 * min(lane, 11));
+                const float a = lane < 12 ? sv.x : (lane == 12 ? tsum.x : (lane == 13 ? tsum.z : 0.0f));
+                const float b = lane < 12 ? sv.y : (lane == 12 ? tsum.y : (lane == 13 ? tsum.w : 0.0f));
+                u32x4 o;
+                o.x = tag; o.y = __float_as_uint(a); o.z = tag; o.w = __float_as_uint(b);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (base + tile * kRecUnits + lane) * 16, 0, 16);   // aux 16 = sc1
+            }
+        }
+#ifdef C3D_STAMPS
+        if (last && blockIdx.x == 0 && threadIdx.x == 0) for (int k = 0; k < 10; ++k) g_rstamps[k] = racc[k];
+#endif
+        if (last) {                                 // hand the state back to the ordinary buffers
             if (finisher) {
+                const AnnealIO* o = late_pointers(io);
+                float* xout = o->xout;
+                float* vout = o->vout;
                 xout[ix] = xn; xout[iy] = yn; xout[iz] = zn;
                 vout[ix] = vcx; vout[iy] = vcy; vout[iz] = vcz;
             }
-            if (tid == 0) {
-                reinterpret_cast<float4*>(pout)[(size_t)rep * m.ntiles + tile] = tsum;
-                if (tile == 0) sout[rep] = st;
-            }
-            break;
+            return;
         }
-
-        // ---- publish this tile's record for step s+1 ---------------------------------------------
-        const unsigned tag = (unsigned)s + 1u;
-        const int base = (((s + 1) & 1) * m.nrep + rep) * units;
-        if (wave == 0 && lane < kRecUnits) {
-            float a, b;
-            if (lane < 12) { a = stage[2 * lane]; b = stage[2 * lane + 1]; }
-            else if (lane == 12) { a = tsum.x; b = tsum.y; }
-            else if (lane == 13) { a = tsum.z; b = tsum.w; }
-            else { a = 0.0f; b = 0.0f; }
-            u32x4 o;
-            o.x = tag; o.y = __float_as_uint(a); o.z = tag; o.w = __float_as_uint(b);
-            __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (base + tile * kRecUnits + lane) * 16, 0, 16);   // aux 16 = sc1
-        }
-        // ---- gather the replica's records of step s+1 into LDS ---------------------------------
+        RSTAMP(6);                                  // publish
+        // ---- gather the replica's records of step s+1 into LDS: all loads in flight, one wait, re-read
+        //      until every tag matches (a thread with fewer than KU units re-reads the replica's last one)
         {
             u32x4 v[KU];
             unsigned spins = 0;
             for (;;) {
                 bool ok = true;
+                asm volatile("" ::: "memory");     // the loads below must be re-issued on every sweep
 #pragma unroll
                 for (int k = 0; k < KU; ++k) {
-                    const int u = tid + BLOCK * k;
-                    if (u < units) {
-                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + u) * 16, 0, 16);
-                        ok &= v[k].x == tag && v[k].z == tag;
-                    }
+                    const int u = min(tid + BLOCK * k, ulast);
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + u) * 16, 0, 16);
                 }
+#pragma unroll
+                for (int k = 0; k < KU; ++k) ok &= v[k].x == tag && v[k].z == tag;
+#ifdef C3D_STAMPS
+                if (blockIdx.x == 0 && threadIdx.x == 0) racc[9] += 1;
+#endif
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1u << 21)) {         // ~2 s: the tiles of this replica are not all resident
@@ -180,73 +224,73 @@ __global__ __launch_bounds__(256, 5) void k_anneal(
                     return;
                 }
             }
+            RSTAMP(7);                              // gather: sweeps until every tag matches
 #pragma unroll
             for (int k = 0; k < KU; ++k) {
-                const int u = tid + BLOCK * k;
-                if (u < units) {
-                    const int r = u / kRecUnits, qd = u % kRecUnits;
-                    const int cat = qd >> 2, within = (qd & 3) * 2;
-                    const float2 val = make_float2(__uint_as_float(v[k].y), __uint_as_float(v[k].w));
-                    if (cat < 3) *reinterpret_cast<float2*>(smem + cat * NPAD + r * kTileRows + within) = val;
-                    else if (qd < 14) *reinterpret_cast<float2*>(ps + r * 4 + within) = val;
-                }
+                float* const dst = tid + BLOCK * k <= ulast ? dst0 + k * dstride : dump;
+                *reinterpret_cast<float2*>(dst) = make_float2(__uint_as_float(v[k].y), __uint_as_float(v[k].w));
             }
         }
+      }
     }
 }
 
+#ifdef C3D_STAMPS
+hipError_t read_resident_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rstamps), sizeof(unsigned long long) * 16); }
+#endif
+
 bool anneal_supported(const DevModel& m) { return m.npad <= 1024 && m.rpw == 2; }
 
-static size_t anneal_lds_bytes(int nb) { return sizeof(float) * ((size_t)3 * 256 * nb + 4 * (256 * nb / kTileRows) + kRecValues + 4 * (kTileRows / 2)); }
+static size_t anneal_lds_bytes(int nb) { return sizeof(float) * ((size_t)3 * 256 * nb + 4 * (256 * nb / kTileRows) + kRecValues + 4 * (kTileRows / 2) + 4) + 128; }
 
 size_t anneal_record_bytes(const DevModel& m) { return (size_t)2 * m.nrep * m.ntiles * kRecUnits * 16; }
 
 template <int POT, bool GEN, int NB>
 static hipError_t anneal_go(bool query, int* blocks_per_cu, const DevModel& m, const DevFire& fp, const AnnealIO* io,
-                            const float* tgt, void* rec, const DevStep* steps, int nsteps, unsigned* timeout, hipStream_t s) {
+                            const float* tgt, void* rec, const StepRun* runs, int nruns, int nsteps, unsigned* timeout, hipStream_t s) {
     const size_t lds = anneal_lds_bytes(NB);
     if (query) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_anneal<POT, GEN, NB>, 256, lds);
     hipLaunchKernelGGL((k_anneal<POT, GEN, NB>), dim3(m.nrep * m.ntiles), dim3(256), lds, s, io, tgt,
-                       reinterpret_cast<u32x4*>(rec), steps, nsteps, timeout, m, fp);
+                       reinterpret_cast<u32x4*>(rec), runs, nruns, nsteps, timeout, m, fp);
     return hipGetLastError();
 }
 template <int POT, bool GEN>
 static hipError_t anneal_nb(bool query, int* bpc, const DevModel& m, const DevFire& fp, const AnnealIO* io, const float* tgt, void* rec,
-                            const DevStep* steps, int nsteps, unsigned* timeout, hipStream_t s) {
+                            const StepRun* runs, int nruns, int nsteps, unsigned* timeout, hipStream_t s) {
     switch (m.npad / 256) {
-        case 1: return anneal_go<POT, GEN, 1>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
-        case 2: return anneal_go<POT, GEN, 2>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
-        case 3: return anneal_go<POT, GEN, 3>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
-        default: return anneal_go<POT, GEN, 4>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
+        case 1: return anneal_go<POT, GEN, 1>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
+        case 2: return anneal_go<POT, GEN, 2>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
+        case 3: return anneal_go<POT, GEN, 3>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
+        default: return anneal_go<POT, GEN, 4>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
     }
 }
 static hipError_t anneal_dispatch(bool query, int* bpc, const DevModel& m, const DevFire& fp, const AnnealIO* io, const float* tgt,
-                                  bool general_tail, void* rec, const DevStep* steps, int nsteps, unsigned* timeout, hipStream_t s) {
+                                  bool general_tail, void* rec, const StepRun* runs, int nruns, int nsteps, unsigned* timeout, hipStream_t s) {
     if (!general_tail) {
         switch (m.noe_pot) {
-            case 0: return anneal_nb<0, false>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
-            case 1: return anneal_nb<1, false>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
-            default: return anneal_nb<2, false>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
+            case 0: return anneal_nb<0, false>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
+            case 1: return anneal_nb<1, false>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
+            default: return anneal_nb<2, false>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
         }
     }
     switch (m.noe_pot) {
-        case 0: return anneal_nb<0, true>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
-        case 1: return anneal_nb<1, true>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
-        default: return anneal_nb<2, true>(query, bpc, m, fp, io, tgt, rec, steps, nsteps, timeout, s);
+        case 0: return anneal_nb<0, true>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
+        case 1: return anneal_nb<1, true>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
+        default: return anneal_nb<2, true>(query, bpc, m, fp, io, tgt, rec, runs, nruns, nsteps, timeout, s);
     }
 }
 
 // workgroups of this kernel that can be resident per CU (occupancy API, capped as the hardware admits them)
 hipError_t anneal_blocks_per_cu(const DevModel& m, bool general_tail, int* blocks_per_cu) {
     DevFire fp{};
-    hipError_t e = anneal_dispatch(true, blocks_per_cu, m, fp, nullptr, nullptr, general_tail, nullptr, nullptr, 0, nullptr, nullptr);
+    hipError_t e = anneal_dispatch(true, blocks_per_cu, m, fp, nullptr, nullptr, general_tail, nullptr, nullptr, 0, 0, nullptr, nullptr);
     if (e == hipSuccess && *blocks_per_cu > 7) *blocks_per_cu = 7;   // .sgpr_count <= 96 (Makefile prints it): 7 admitted
     return e;
 }
 
 hipError_t launch_anneal(const DevModel& m, const DevFire& fp, const AnnealIO* io, const float* tgt, bool general_tail, void* rec,
-                         const DevStep* steps, int nsteps, unsigned* timeout, hipStream_t s) {
-    return anneal_dispatch(false, nullptr, m, fp, io, tgt, general_tail, rec, steps, nsteps, timeout, s);
+                         const StepRun* runs, int nruns, int nsteps, unsigned* timeout, hipStream_t s) {
+    return anneal_dispatch(false, nullptr, m, fp, io, tgt, general_tail, rec, runs, nruns, nsteps, timeout, s);
 }
 
 AnnealIO anneal_io(const DevBuffers& b, int parity) {

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_handoff(u32x4* __restrict__ rec, Params
             unsigned spins = 0;
             do {
                 ok = true;
+                asm volatile("" ::: "memory");   // re-issue the loads on every sweep
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int u = tid + 256 * k;
