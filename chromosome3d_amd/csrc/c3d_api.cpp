@@ -97,7 +97,7 @@ struct c3d_ctx {
     int rpw = 2;
     int stage_dma = 1;
     int graph_chunk = 256;
-    bool resident = false;                 // multi-step resident kernel where the problem fits (c3d_resident.hip)
+    int resident = -1;                     // resident multi-step kernel (c3d_resident.hip): 1 on, 0 off, -1 where it is faster
     int resident_min_ops = 4;              // shorter ranges go step by step
 
     std::vector<int32_t> h_dist10;   // n*n, from K1 (empty when restraints came from a tbl)
@@ -120,7 +120,8 @@ struct c3d_ctx {
     void* d_rec = nullptr;
     size_t rec_bytes = 0;
     unsigned* d_tmo = nullptr;
-    bool resident_pending = false;         // a resident launch has not had its timeout word checked yet
+    bool inject_timeout = false;           // test hook: pretend the next resident launch timed out
+    int resident_fallbacks = 0;            // resident launches abandoned for the per-step path (see run_resident)
     int resident_cap = -1;                 // workgroups per CU of the resident kernel (-1: not queried)
     int num_cus = 0;
 
@@ -274,6 +275,9 @@ bool resident_ok(c3d_ctx* c) {
     if (!c->resident || !c->d_rec) return false;
     const c3d::DevModel m = dev_model(c);
     if (!c3d::anneal_supported(m)) return false;
+    // measured on MI355X (profiles/r01_resident_crossover.txt): the resident kernel wins while its waves
+    // (4 per workgroup) stay below ~2.9 per SIMD, the per-step graph path above that
+    if (c->resident < 0 && (long)c->nrep * c->ntiles * 4 > (long)(2.9 * 4 * c->num_cus)) return false;
     if (c->resident_cap < 0) {
         int cap = 0;
         if (c3d::anneal_blocks_per_cu(m, general_tail(m), &cap) != hipSuccess) cap = 0;
@@ -282,7 +286,7 @@ bool resident_ok(c3d_ctx* c) {
     return (long)c->nrep * c->ntiles <= (long)c->resident_cap * c->num_cus;
 }
 
-int run_resident(c3d_ctx* c, size_t nops) {
+int run_resident(c3d_ctx* c, size_t nops, bool* ran) {
     // consecutive ops with identical parameters become one run (a FIRE stage is 2 runs, the cool ramp 81)
     std::vector<c3d::StepRun> runs;
     for (size_t k = 0; k < nops; ++k) {
@@ -299,10 +303,29 @@ int run_resident(c3d_ctx* c, size_t nops) {
     HIP_TRY(hipMemcpyAsync(c->d_runs, runs.data(), sizeof(c3d::StepRun) * runs.size(), hipMemcpyHostToDevice, c->stream));
     const c3d::DevModel m = dev_model(c);
     HIP_TRY(hipMemsetAsync(c->d_rec, 0, c->rec_bytes, c->stream));
+    if (c->inject_timeout) {
+        const unsigned one = 1;
+        HIP_TRY(hipMemcpyAsync(c->d_tmo, &one, sizeof(one), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->inject_timeout = false;
+    }
     hipError_t e = c3d::launch_anneal(m, dev_fire(c), c->d_io + c->parity, c->buf.tgt, general_tail(m), c->d_rec,
                                       c->d_runs, (int)runs.size(), (int)nops, c->d_tmo, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("resident launch: ") + hipGetErrorString(e));
-    c->resident_pending = true;
+    // The launch reads parity p and writes parity p^1 only in its last step, so its inputs are intact whatever
+    // happens: if a tile gave up waiting (its replica's workgroups were not all resident, e.g. another process
+    // fills the GPU), switch this context to the per-step path and let the caller run the same ops there.
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned t = 0;
+    HIP_TRY(hipMemcpy(&t, c->d_tmo, sizeof(t), hipMemcpyDeviceToHost));
+    if (t) {
+        HIP_TRY(hipMemset(c->d_tmo, 0, sizeof(t)));
+        c->resident = 0;
+        ++c->resident_fallbacks;
+        *ran = false;
+        return C3D_OK;
+    }
+    *ran = true;
     c->parity ^= 1;
     for (size_t k = 0; k < nops; ++k)
         if (c->program[c->pc + k].counted) { ++c->steps_done; ++c->last_steps; }
@@ -311,24 +334,14 @@ int run_resident(c3d_ctx* c, size_t nops) {
     return C3D_OK;
 }
 
-// after a synchronisation: did a resident launch give up waiting for a tile record?
-int check_resident(c3d_ctx* c) {
-    if (!c->resident_pending) return C3D_OK;
-    c->resident_pending = false;
-    unsigned t = 0;
-    HIP_TRY(hipMemcpy(&t, c->d_tmo, sizeof(t), hipMemcpyDeviceToHost));
-    if (t) {
-        HIP_TRY(hipMemset(c->d_tmo, 0, sizeof(t)));
-        return fail(C3D_ERR_HIP, "resident anneal kernel: a tile waited ~2 s for its replica's records (workgroups not co-resident; "
-                                 "set option resident=0)");
-    }
-    return C3D_OK;
-}
-
 // run program ops [pc, pc + nops): eager or via cached graphs; every replica group advances on its
 // own stream (fork from / join into stream 0 around the call)
 int run_ops(c3d_ctx* c, size_t nops) {
-    if (nops >= (size_t)c->resident_min_ops && nops < (size_t)INT32_MAX && resident_ok(c)) return run_resident(c, nops);
+    if (nops >= (size_t)c->resident_min_ops && nops < (size_t)INT32_MAX && resident_ok(c)) {
+        bool ran = false;
+        const int rc = run_resident(c, nops, &ran);
+        if (rc != C3D_OK || ran) return rc;
+    }
     const int G = active_groups(c);
     if (G > 1) {
         HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
@@ -398,7 +411,7 @@ int end_timing(c3d_ctx* c) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
-    return check_resident(c);
+    return C3D_OK;
 }
 
 // max over replicas of the RMS force from the FIRE partial sums of the current parity
@@ -573,7 +586,8 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         drop_graphs(c);
         return C3D_OK;
     }
-    if (!strcmp(key, "resident")) { c->resident = value != 0; return C3D_OK; }
+    if (!strcmp(key, "resident")) { c->resident = value < 0 ? -1 : (value != 0); return C3D_OK; }
+    if (!strcmp(key, "resident_inject_timeout")) { c->inject_timeout = value != 0; return C3D_OK; }   // test hook
     if (!strcmp(key, "resident_min_ops")) { c->resident_min_ops = value < 1 ? 1 : (int)value; return C3D_OK; }
     if (!strcmp(key, "stage_dma")) { c->stage_dma = value != 0; drop_graphs(c); return C3D_OK; }
     if (!strcmp(key, "graph_chunk")) {

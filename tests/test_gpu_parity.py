@@ -400,3 +400,38 @@ def test_device_scoring_equals_host_scoring(solver, cid):
         assert np.allclose(rho, host_rho, rtol=0, atol=1e-12)
     sat2, dev2, none = solver.score(None)
     assert none is None and np.array_equal(sat2, sat) and np.array_equal(dev2, dev)
+
+
+def _anneal(solver, cid, nrep, resident, inject=False):
+    from chromosome3d_amd import default_model, default_schedule
+    solver.set_model(default_model())
+    solver.set_if_matrix(load_if(cid))
+    solver.set_schedule(default_schedule(300), None, 1e-2, 100)
+    solver.set_option("resident", resident)
+    solver.set_option("resident_inject_timeout", 1 if inject else 0)
+    solver.init_replicas(nrep, 82364, 0)
+    solver.run()
+    out = solver.coords(), solver.velocities(), solver.energies(), solver.last_timing()
+    solver.set_option("resident", -1)
+    return out
+
+
+@pytest.mark.parametrize("cid,nrep", [("chr21_1mb", 4), ("chr19_500kb", 3), ("chr1_500kb", 3)])
+def test_resident_kernel_is_bit_identical_to_per_step_path(solver, cid, nrep):
+    """The multi-step resident kernel (tile records handed between workgroups inside one launch) and the
+    one-launch-per-step path run the same arithmetic: the whole anneal, early exit included, ends in the
+    same bits."""
+    xa, va, ea, ta = _anneal(solver, cid, nrep, 0)
+    xb, vb, eb, tb = _anneal(solver, cid, nrep, 1)
+    assert ta[1] == tb[1]                       # same number of SA steps (same early exit)
+    assert tb[2] < 40 < ta[2]                   # a handful of launches instead of thousands
+    assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(ea, eb)
+
+
+def test_resident_launch_that_times_out_falls_back_to_per_step(solver):
+    """A resident launch whose tiles cannot all be resident gives up (bounded spins) and leaves its inputs
+    intact; the host then runs the same steps on the per-step path.  The timeout is injected."""
+    xa, va, ea, ta = _anneal(solver, "chr21_1mb", 4, 0)
+    xb, vb, eb, tb = _anneal(solver, "chr21_1mb", 4, 1, inject=True)
+    assert tb[2] > 40                           # ran step by step after the abandoned launch
+    assert np.array_equal(xa, xb) and np.array_equal(ea, eb)
