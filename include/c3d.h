@@ -101,7 +101,12 @@ int c3d_num_restraints(const c3d_ctx* ctx);
 int c3d_set_model(c3d_ctx* ctx, const c3d_model* m);
 int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const c3d_fire_params* fire,
                      float gtol, int check_every);
-/* use_graph != 0: replay the step sequence from hipGraphs (default 1). */
+/* Execution knobs (results do not depend on them except rows_per_wave, which changes summation order):
+ *   resident        -1 (default) / 0 / 1: run step ranges as ONE resident launch (c3d_resident.hip) where that
+ *                   is faster (small and medium N) / never / whenever the workgroups fit on the GPU
+ *   use_graph       != 0: per-step path replays hipGraphs (default 1)
+ *   replica_groups  1..4 stream groups of the per-step path (default 2);  graph_chunk, rows_per_wave,
+ *   stage_dma       tuning and test knobs of the per-step kernel */
 int c3d_set_option(c3d_ctx* ctx, const char* key, double value);
 
 /* --- replicas ----------------------------------------------------------------------- */
