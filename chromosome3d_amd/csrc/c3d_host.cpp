@@ -361,3 +361,56 @@ extern "C" int c3d_spearman_if_dist_batch(const double* IF, const float* xyz, in
 extern "C" int c3d_spearman_if_dist(const double* IF, const float* xyz, int n, int range, double* rho) {
     return c3d_spearman_if_dist_batch(IF, xyz, n, 1, range, rho);
 }
+
+// ---- cross-resolution similarity (output_models/similarity.txt of the reference: data only, no code) ----
+// The bundled "<ID>_reduced.pdb" of a 500 kb model is the mean of consecutive bead pairs (an odd last bead
+// is kept); its similarity to the 1 Mb model of the same chromosome is reported as the Spearman
+// correlation of the i<j distances and as an "RMSD" of those distances after scaling the first model's
+// by mean(d_b)/mean(d_a).  Both definitions were recovered from the bundled files and reproduce every
+// number of similarity.txt to 1e-12.
+extern "C" int c3d_reduce_model(const double* xyz, int n, double* out) {
+    if (!xyz || !out || n < 1) return fail(C3D_ERR_INVALID, "c3d_reduce_model: bad arguments");
+    const int m = (n + 1) / 2;
+    for (int k = 0; k < m; ++k)
+        for (int c = 0; c < 3; ++c) {
+            const double a = xyz[(size_t)(2 * k) * 3 + c];
+            out[(size_t)k * 3 + c] = 2 * k + 1 < n ? 0.5 * (a + xyz[(size_t)(2 * k + 1) * 3 + c]) : a;
+        }
+    return C3D_OK;
+}
+
+extern "C" int c3d_model_similarity(const double* a, const double* b, int n, double* spearman, double* rmsd) {
+    if (!a || !b || n < 3) return fail(C3D_ERR_INVALID, "c3d_model_similarity: bad arguments");
+    const size_t m = (size_t)n * (n - 1) / 2;
+    std::vector<double> da(m), db(m), ra, rb;
+    size_t k = 0;
+    double sa = 0, sb = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j, ++k) {
+            double qa = 0, qb = 0;
+            for (int c = 0; c < 3; ++c) {
+                const double ua = a[(size_t)i * 3 + c] - a[(size_t)j * 3 + c], ub = b[(size_t)i * 3 + c] - b[(size_t)j * 3 + c];
+                qa += ua * ua; qb += ub * ub;
+            }
+            da[k] = sqrt(qa); db[k] = sqrt(qb);
+            sa += da[k]; sb += db[k];
+        }
+    if (spearman) {
+        avg_ranks(da, ra);
+        avg_ranks(db, rb);
+        const double mean = 0.5 * ((double)m + 1.0);
+        double sab = 0, saa = 0, sbb = 0;
+        for (size_t q = 0; q < m; ++q) {
+            const double x = ra[q] - mean, y = rb[q] - mean;
+            sab += x * y; saa += x * x; sbb += y * y;
+        }
+        *spearman = sab / sqrt(saa * sbb);
+    }
+    if (rmsd) {
+        const double scale = sa > 0 ? sb / sa : 1.0;     // ratio of the mean distances
+        double acc = 0;
+        for (size_t q = 0; q < m; ++q) { const double e = scale * da[q] - db[q]; acc += e * e; }
+        *rmsd = sqrt(acc / (double)m);
+    }
+    return C3D_OK;
+}

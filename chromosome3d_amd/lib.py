@@ -70,6 +70,8 @@ SIGNATURES = {
     "c3d_get_energies": (_i, [_vp, _dp]),
     "c3d_score_replicas": (_i, [_vp, _dp, _i, _i32p, _dp, _dp]),
     "c3d_rank": (_i, [_vp, _i32p]),
+    "c3d_reduce_model": (_i, [_dp, _i, _dp]),
+    "c3d_model_similarity": (_i, [_dp, _dp, _i, _dp, _dp]),
     "c3d_parse_if_file": (_i, [C.c_char_p, C.POINTER(_dp), C.POINTER(_i)]),
     "c3d_free": (None, [_vp]),
     "c3d_write_front_half": (_i, [_i32p, _i, _i, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_i)]),

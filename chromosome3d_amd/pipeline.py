@@ -124,6 +124,25 @@ def spearman_IF_models(IF, xyz, rng=3):
     return rho
 
 
+def reduce_model(xyz):
+    """500 kb model -> 1 Mb resolution as the reference's `*_reduced.pdb` files: mean of consecutive bead pairs."""
+    x = np.ascontiguousarray(xyz, dtype=np.float64)
+    out = np.empty(((x.shape[0] + 1) // 2, 3), dtype=np.float64)
+    _l.check(_l.load().c3d_reduce_model(_l.dptr(x), x.shape[0], _l.dptr(out)))
+    return out
+
+
+def model_similarity(xa, xb):
+    """(Spearman, "RMSD") of two models' pairwise distances as in output_models/similarity.txt; the longer
+    model is cut to the shorter one's length (a reduced 500 kb model can have one bead more or less)."""
+    n = min(len(xa), len(xb))
+    a = np.ascontiguousarray(np.asarray(xa, dtype=np.float64)[:n])
+    b = np.ascontiguousarray(np.asarray(xb, dtype=np.float64)[:n])
+    rho, rmsd = C.c_double(), C.c_double()
+    _l.check(_l.load().c3d_model_similarity(_l.dptr(a), _l.dptr(b), n, C.byref(rho), C.byref(rmsd)))
+    return rho.value, rmsd.value
+
+
 def build_models(solver, model_count=MODELCOUNT, seed=MD_SEED, first_replica=0, model=None, stages=None, fire=None,
                  gtol=1e-2, check_every=250):
     """The replacement of `cns_solve < dgsa.inp` (:254-289): runs the whole annealing schedule

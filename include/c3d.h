@@ -175,6 +175,14 @@ int c3d_spearman_if_dist(const double* IF, const float* xyz, int n, int range, d
 /* the same for n_models models (n_models*n*3 coordinates) of one matrix: IF is ranked once */
 int c3d_spearman_if_dist_batch(const double* IF, const float* xyz, int n, int n_models, int range, double* rho);
 
+/* Cross-resolution check of the reference's output_models/similarity.txt (data only; the definitions
+ * were recovered from the bundled models and reproduce its numbers to 1e-12):
+ *   c3d_reduce_model      mean of consecutive bead pairs (an odd last bead is kept): out has (n+1)/2 beads
+ *   c3d_model_similarity  two models of n beads: Spearman of the i<j distances, and the RMS difference of
+ *                         those distances after scaling a's by mean(d_b)/mean(d_a) ("RMSD" in that file) */
+int c3d_reduce_model(const double* xyz, int n, double* out);
+int c3d_model_similarity(const double* a, const double* b, int n, double* spearman, double* rmsd);
+
 #ifdef __cplusplus
 }
 #endif
