@@ -15,6 +15,6 @@ for name, IF, nrep, nmin in (("config2 chr21_1mb", load_if("chr21_1mb"), 20, 300
     ms, steps, la = s.last_timing()
     R = s.num_restraints
     B = 4 * R + 72 * n
-    print(f"{name}: N={n} R={R} replicas={nrep}: {1e3 * ms / la:.2f} us/step, {nrep * steps / ms * 1e3 / 1e6:.3f} M replica-steps/s, "
+    print(f"{name}: N={n} R={R} replicas={nrep}: {1e3 * ms / steps:.2f} us/step ({la} launches), {nrep * steps / ms * 1e3 / 1e6:.3f} M replica-steps/s, "
           f"full schedule {ms:.1f} ms, algorithmic {nrep * steps * B / (ms * 1e-3) / 1e9:.0f} GB/s ({nrep * steps * B / (ms * 1e-3) / 8e12:.3f} of 8 TB/s), "
           f"pair rate {nrep * steps * n * n / (ms * 1e-3) / 1e12:.2f} Tpair/s", flush=True)
