@@ -221,7 +221,8 @@ void build_program(c3d_ctx* c) {
 int upload_targets(c3d_ctx* c, const std::vector<float>& enc) {
     if (c->buf.tgt) { hipFree(c->buf.tgt); c->buf.tgt = nullptr; }
     HIP_TRY(hipMalloc(&c->buf.tgt, sizeof(float) * enc.size()));
-    HIP_TRY(hipMemcpy(c->buf.tgt, enc.data(), sizeof(float) * enc.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->buf.tgt, enc.data(), sizeof(float) * enc.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return C3D_OK;
 }
 
@@ -317,9 +318,10 @@ int run_resident(c3d_ctx* c, size_t nops, bool* ran) {
     // fills the GPU), switch this context to the per-step path and let the caller run the same ops there.
     HIP_TRY(hipStreamSynchronize(c->stream));
     unsigned t = 0;
-    HIP_TRY(hipMemcpy(&t, c->d_tmo, sizeof(t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&t, c->d_tmo, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (t) {
-        HIP_TRY(hipMemset(c->d_tmo, 0, sizeof(t)));
+        HIP_TRY(hipMemsetAsync(c->d_tmo, 0, sizeof(t), c->stream));
         c->resident = 0;
         ++c->resident_fallbacks;
         *ran = false;
@@ -518,7 +520,8 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     for (int g = 1; ok && g < c3d_ctx::kMaxGroups; ++g)
         ok = hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipMalloc(&c->d_tmo, 16) == hipSuccess && hipMemset(c->d_tmo, 0, 16) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_tmo, 16) == hipSuccess && hipMemsetAsync(c->d_tmo, 0, 16, c->stream) == hipSuccess &&
+         hipStreamSynchronize(c->stream) == hipSuccess;
     if (!ok) {
         c3d_destroy(c);
         return fail(C3D_ERR_HIP, "cannot create HIP stream/events");
@@ -696,7 +699,8 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
             HIP_TRY(hipMalloc(&c->d_rec, c->rec_bytes));
             const c3d::AnnealIO io[2] = {c3d::anneal_io(c->buf, 0), c3d::anneal_io(c->buf, 1)};
             HIP_TRY(hipMalloc(&c->d_io, sizeof(io)));
-            HIP_TRY(hipMemcpy(c->d_io, io, sizeof(io), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(c->d_io, io, sizeof(io), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
         }
         c->have_replicas = true;
     }
@@ -734,16 +738,19 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
     }
     std::vector<float> soa;
     pack(c, x.data(), soa, true);
-    HIP_TRY(hipMemcpy(c->buf.X[0], soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->buf.X[1], soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->buf.X[0], soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->buf.X[1], soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     pack(c, v.data(), soa, false);
-    HIP_TRY(hipMemcpy(c->buf.Vinit, soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->buf.Vinit, soa.data(), sizeof(float) * nf, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipMemset(c->buf.V[k], 0, sizeof(float) * nf));
-        HIP_TRY(hipMemset(c->buf.P[k], 0, sizeof(float) * 4 * (size_t)nrep * c->ntiles * c3d::kTileRows));
-        HIP_TRY(hipMemset(c->buf.S[k], 0, sizeof(c3d::FireState) * nrep));
+        HIP_TRY(hipMemsetAsync(c->buf.V[k], 0, sizeof(float) * nf, c->stream));
+        HIP_TRY(hipMemsetAsync(c->buf.P[k], 0, sizeof(float) * 4 * (size_t)nrep * c->ntiles * c3d::kTileRows, c->stream));
+        HIP_TRY(hipMemsetAsync(c->buf.S[k], 0, sizeof(c3d::FireState) * nrep, c->stream));
     }
-    HIP_TRY(hipMemset(c->d_feval, 0, sizeof(float) * nf));
+    HIP_TRY(hipMemsetAsync(c->d_feval, 0, sizeof(float) * nf, c->stream));
     c->pc = 0; c->parity = 0; c->steps_done = 0;
     return C3D_OK;
 }
@@ -786,13 +793,15 @@ extern "C" int c3d_set_coords(c3d_ctx* c, const float* xyz) {
     std::vector<float> soa;
     pack(c, xyz, soa, true);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(c->buf.X[c->parity], soa.data(), sizeof(float) * soa.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->buf.X[c->parity], soa.data(), sizeof(float) * soa.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return C3D_OK;
 }
 static int get_soa(c3d_ctx* c, const float* dev, float* aos) {
     std::vector<float> soa(c->rep_floats * c->nrep);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(soa.data(), dev, sizeof(float) * soa.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(soa.data(), dev, sizeof(float) * soa.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     unpack(c, soa, aos);
     return C3D_OK;
 }
