@@ -1,10 +1,13 @@
 // c3d_api.cpp — C-ABI host of libc3d.so: context, device buffers, schedule -> launch program,
-// hipGraph replay, timing.  Compiled with hipcc (-x hip) for the HIP runtime API only; the
-// kernels live in c3d_device.hip.
+// hipGraph replay, resident launches, timing.  Compiled with hipcc (-x hip) for the HIP runtime API only;
+// the kernels live in c3d_device.hip (per-step), c3d_resident.hip (multi-step), c3d_embed.hip, c3d_score.hip.
 //
 // Reference boundary: chromosome3D.pl:254-289 (build_models: `cns_solve < dgsa.inp`) and the
 // deck it writes (:882-1846).  What CNS does per model (deck :1574-1829) becomes a flat
-// "program" of SA-step launches; each launch advances every replica by one step.
+// "program" of SA steps; a range of it runs either as one launch per step (two replica groups on two
+// streams, replayed from hipGraphs) or as ONE resident launch (run_resident), whichever is faster for
+// the problem size.  Every copy and memset is ordered on the context's own stream: contexts of different
+// host threads never meet on the legacy stream.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

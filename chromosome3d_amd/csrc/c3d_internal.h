@@ -22,7 +22,7 @@ struct DevModel {
     int n, npad, ntiles, nrep;
     int rep_base, nrep_g;          // replica group of this launch: [rep_base, rep_base + nrep_g)
     int stage_dma;                 // 1: coordinates staged with global_load_lds (async), 0: through registers
-    int rpw;                       // rows per wave of the step kernel (1, 2 or 4); waves/WG = 16/rpw
+    int rpw;                       // rows per wave of the step kernel (1, 2 or 4); waves/WG = kTileRows/rpw
     int noe_pot, ang_mode, rep_sep;
     float rs, tail_c, tail_b;      // soft tail: dE/dD = tail_c - tail_b / D^2  (D > rs)
     float k_bond2, b0;             // 2*k_bond

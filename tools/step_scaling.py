@@ -26,4 +26,4 @@ for cid in ("chr21_1mb", "chr1_500kb"):
                 s.init_replicas(nrep, 1, 0)
                 s.run_steps(10**6)
                 ms, steps, la = s.last_timing()
-                print(f"{cid:11s} n={IF.shape[0]:4d} {kind:4s} rpw={rpw} nrep={nrep:4d}  {1e3*ms/la:8.3f} us/launch  {nrep*steps/ms*1e3/1e6:8.3f} M replica-steps/s", flush=True)
+                print(f"{cid:11s} n={IF.shape[0]:4d} {kind:4s} rpw={rpw} nrep={nrep:4d}  {1e3*ms/steps:8.3f} us/step  {nrep*steps/ms*1e3/1e6:8.3f} M replica-steps/s", flush=True)
