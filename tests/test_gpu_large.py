@@ -63,3 +63,27 @@ def test_anneal_recovers_synthetic_structure(solver, big):
         assert spearmanr(dt, dm)[0] > 0.9
         assert spearmanr(IF[i[keep], j[keep]], dm)[0] < -0.85
     print(f"N=2500 x 2 replicas: {steps} SA steps in {ms:.1f} ms = {1e3 * ms / launches:.1f} us/step")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nrep", [(256, 3), (257, 3), (600, 2), (1000, 2), (9, 5)])
+def test_resident_kernel_every_column_block_count(solver, n, nrep):
+    """Resident kernel instantiations for 1..4 column blocks (targets held in 8..32 VGPRs), the block
+    boundary N = 256 / 257 and a single-tile problem: same bits as the per-step path after MD and FIRE steps."""
+    from chromosome3d_amd import default_model, make_stages
+    from tests.util import synthetic_if
+    IF, _ = synthetic_if(n, seed=7)
+    out = []
+    for resident in (0, 1):
+        solver.set_model(default_model())
+        solver.set_if_matrix(IF)
+        solver.set_schedule(make_stages([(2, 12, 0.0, 1.0, 1.0, 0.85, 0.0), (0, 20, 0.003, 1.0, 0.5, 0.9, 2000.0),
+                                         (1, 20, 0.005, 1.0, 0.01, 0.9, 500.0), (2, 15, 0.0, 1.0, 1.0, 0.85, 0.0)]))
+        solver.set_option("resident", resident)
+        solver.init_replicas(nrep, 3, 0)
+        solver.run_steps(10 ** 6)
+        out.append((solver.coords(), solver.velocities(), solver.last_timing()[2]))
+    solver.set_option("resident", -1)
+    assert out[1][2] == 1 and out[0][2] > 60
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
