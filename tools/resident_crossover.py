@@ -1,6 +1,6 @@
 """Per-step time of the per-step (hipGraph) path vs the resident kernel over every bundled matrix size.
 
-    python tools/resident_crossover.py [replicas=20]
+    python tools/resident_crossover.py [replicas=20] [option=value ...]
 Needs tests/golden/_all (tools/pack_all_inputs.py).  One line per matrix: N, tiles, us/step of both paths
 for the full default schedule (5172 steps, fixed length).
 """
@@ -12,6 +12,7 @@ from chromosome3d_amd import Solver, default_model, default_schedule, default_fi
 
 ALL = os.path.join(ROOT, "tests", "golden", "_all")
 nrep = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+opts = [kv.split("=") for kv in sys.argv[2:]]          # e.g. resident_waves=8
 
 
 def load(cid):
@@ -34,6 +35,8 @@ for n, cid in sizes:
     out = []
     for res in (0, 1):
         s.set_option("resident", res)
+        for k, v in opts:
+            s.set_option(k, float(v))
         for rep in range(2):                      # first pass builds the graphs
             s.init_replicas(nrep, 82364, 0)
             s.run_steps(s.schedule_length)

@@ -15,6 +15,9 @@ def state(cid, nrep, k, resident):
     s.set_schedule(default_schedule(300), None, 0.0, 250)
     s.set_option("resident", resident)
     s.set_option("resident_min_ops", 1)
+    for kv in sys.argv[3:]:
+        key, val = kv.split("=")
+        s.set_option(key, float(val))
     s.init_replicas(nrep, 82364, 0)
     s.run_steps(k)
     return s.coords(), s.velocities()
