@@ -171,3 +171,24 @@ def test_cross_resolution_similarity_reproduces_reference_table(built):
     # a model is identical to itself; scale invariance of both measures
     rho2, rmsd2 = pipeline.model_similarity(b, 3.0 * b)
     assert abs(rho2 - 1.0) < 1e-12 and rmsd2 < 1e-9
+
+
+def test_threaded_parser_is_exact_and_reports_bad_tokens(built, tmp_path):
+    """Files above 8 MB are parsed by one chunk per host thread (two passes).  Same doubles as Python's
+    float() for every entry; a malformed token anywhere, or a missing number, is an error."""
+    from chromosome3d_amd import C3DError, pipeline
+    n = 720
+    rng = np.random.default_rng(5)
+    a = rng.random((n, n)) * 10.0 ** rng.integers(-3, 6, size=(n, n))
+    p = tmp_path / "big.txt"
+    text = "".join(" ".join(repr(float(v)) for v in row) + " \r\n" for row in a)
+    assert len(text) > (8 << 20)
+    p.write_text(text, newline="")
+    assert np.array_equal(pipeline.parse_if_file(str(p)), a)
+    bad = text[: len(text) * 3 // 4] + "x" + text[len(text) * 3 // 4 + 1:]
+    (tmp_path / "bad.txt").write_text(bad, newline="")
+    with pytest.raises(C3DError):
+        pipeline.parse_if_file(str(tmp_path / "bad.txt"))
+    (tmp_path / "short.txt").write_text(text[: text.rstrip().rfind(" ")], newline="")
+    with pytest.raises(C3DError):
+        pipeline.parse_if_file(str(tmp_path / "short.txt"))
