@@ -29,24 +29,23 @@ namespace c3d {
 __device__ unsigned long long g_stamps[16];
 #define C3D_STAMP(k)                                                                   \
     do {                                                                               \
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k] = __builtin_readcyclecounter(); \
+        if (blockIdx.x + blockIdx.y + blockIdx.z == 0 && threadIdx.x == 0) g_stamps[k] = __builtin_readcyclecounter(); \
     } while (0)
 #else
 #define C3D_STAMP(k) do { } while (0)
 #endif
 
 
-// XCD-aware block -> (tile, replica) map.  Blocks b and b+8 share an XCD (round-robin dispatch,
-// a speed assumption only): every workgroup that reads row-tile t of the target matrix gets the
-// same b%8, so each XCD's L2 holds only 1/8 of the matrix and replicas re-use it there.
+// XCD-aware block -> (tile, replica) map.  The grid is (8, replicas of the group, tile groups): blocks are
+// dispatched in linear order x + 8 (y + ny z) and dealt round-robin over the 8 XCDs (a speed assumption only),
+// so every workgroup that reads row-tile t = 8 z + x of the target matrix lands on the XCD of its x: each XCD's
+// L2 holds only 1/8 of the matrix and the replicas re-use it there.  No integer division on the way.
 __device__ __forceinline__ bool block_to_tile(const DevModel& m, int& tile, int& rep) {
-    const int b = blockIdx.x;
-    const int k = b >> 3;
-    rep = m.rep_base + k % m.nrep_g;
-    tile = (k / m.nrep_g) * 8 + (b & 7);
+    rep = m.rep_base + blockIdx.y;
+    tile = blockIdx.z * 8 + blockIdx.x;
     return tile < m.ntiles;
 }
-inline int grid_blocks(const DevModel& m) { return 8 * ((m.ntiles + 7) / 8) * m.nrep_g; }
+inline dim3 grid_blocks(const DevModel& m) { return dim3(8, m.nrep_g, (m.ntiles + 7) / 8); }
 
 
 // ---------------------------------------------------------------------------------------------
@@ -69,6 +68,15 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     constexpr int WAVES = kTileRows / RPW;
     constexpr int BLOCK = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    C3D_STAMP(6);      // before any kernel argument beyond the preloaded ones is needed
+    {   // The 244-byte kernarg block spans four 64-byte lines and the scalar cache is cold at every launch: the
+        // compiler fetches the arguments where they are first used, one ~550-cycle miss after the other.  Touch
+        // the three lines beyond the preloaded pointers at once; the later loads then hit.
+        const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+        unsigned t0, t1, t2;
+        asm volatile("s_load_dword %0, %3, 0x40\n\ts_load_dword %1, %3, 0x80\n\ts_load_dword %2, %3, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2) : "s"(ka) : "memory");
+    }
     int tile, rep;
     if (!block_to_tile(m, tile, rep)) return;
     C3D_STAMP(0);
@@ -88,14 +96,11 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     // ---- 1. every independent global load is issued before anything waits -------------------
     if (m.stage_dma) lds_dma_copy<BLOCK>(xin + roff, smem, 3 * npad, tid);
     else for (int b = 4 * tid; b < 3 * npad; b += 4 * BLOCK) *reinterpret_cast<float4*>(smem + b) = *reinterpret_cast<const float4*>(xin + roff + b);
-    float4 psum = make_float4(0, 0, 0, 0);
-    if (needs_partials) {   // one float4 per tile; ntiles <= 64 for N <= 512
-        const float4* pp = reinterpret_cast<const float4*>(pin) + (size_t)rep * m.ntiles;
-        for (int t = lane; t < m.ntiles; t += 64) {
-            const float4 q = pp[t];
-            psum.x += q.x; psum.y += q.y; psum.z += q.z; psum.w += q.w;
-        }
-    }
+    // the first partial-sum entry of every lane is only ISSUED here: adding it up right away would park the wave
+    // on this cold load before the target and velocity loads below are even on their way
+    const float4* pp = reinterpret_cast<const float4*>(pin) + (size_t)rep * m.ntiles;
+    float4 q0 = make_float4(0, 0, 0, 0);
+    if (needs_partials && lane < m.ntiles) q0 = pp[lane];
     float4 tv[RPW];
     if (p.kind != 4) tile_prefetch<RPW>(m, tgt, row0, lane, 0, tv);
     float vx0 = 0.0f, vy0 = 0.0f, vz0 = 0.0f;
@@ -106,6 +111,14 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     FireState st;
     st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0;
     if (p.kind == 2) st = sin[rep];
+    float4 psum = make_float4(0, 0, 0, 0);
+    if (needs_partials) {   // one float4 per tile; ntiles <= 64 for N <= 512
+        psum.x += q0.x; psum.y += q0.y; psum.z += q0.z; psum.w += q0.w;
+        for (int t = lane + 64; t < m.ntiles; t += 64) {
+            const float4 q = pp[t];
+            psum.x += q.x; psum.y += q.y; psum.z += q.z; psum.w += q.w;
+        }
+    }
     C3D_STAMP(1);
 
     // ---- 2. scalars per wave (no barrier; every wave derives the same values) -----------------
@@ -155,7 +168,7 @@ template <int POT, bool GEN, int RPW>
 static hipError_t launch_step_r(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
                                 hipStream_t s) {
     const int q = par ^ 1;
-    hipLaunchKernelGGL((k_step<POT, GEN, RPW>), dim3(grid_blocks(m)), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
+    hipLaunchKernelGGL((k_step<POT, GEN, RPW>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
                        b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
     return hipGetLastError();
 }
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_eval_forces(const DevModel m, co
 hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float* Fout,
                               bool general_tail, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)3 * m.npad;
-    const dim3 g(grid_blocks(m)), blk(kEvalBlock);
+    const dim3 g = grid_blocks(m), blk(kEvalBlock);
 #define C3D_EVAL(POT, GEN) hipLaunchKernelGGL((k_eval_forces<POT, GEN>), g, blk, lds, s, m, p, b.tgt, b.X[parity], Fout)
     if (!general_tail) {
         if (m.noe_pot == 0) C3D_EVAL(0, false); else if (m.noe_pot == 1) C3D_EVAL(1, false); else C3D_EVAL(2, false);

@@ -24,7 +24,7 @@ for cid in ("chr21_1mb", "chr1_500kb"):
                     s.run_steps(1)
                     buf = (C.c_ulonglong * 16)()
                     L.c3d_debug_stamps(buf)
-                    t = np.array(buf[:6], dtype=np.int64)
-                    acc.append(np.diff(t))
+                    t = np.array(buf[:7], dtype=np.int64)
+                    acc.append(np.concatenate([np.diff(t[:6]), [t[0] - t[6]]]))
                 a = np.median(np.array(acc), axis=0)
-                print(f"{cid} {kind} rpw={rpw} nrep={nrep}: cycles loads-issue {a[0]:.0f} | scalars+stage {a[1]:.0f} | barrier {a[2]:.0f} | pair loop+reduce {a[3]:.0f} | epilogue {a[4]:.0f} | total {a.sum():.0f}", flush=True)
+                print(f"{cid} {kind} rpw={rpw} nrep={nrep}: cycles loads-issue {a[0]:.0f} | scalars+stage {a[1]:.0f} | barrier {a[2]:.0f} | pair loop+reduce {a[3]:.0f} | epilogue {a[4]:.0f} | total {a[:5].sum():.0f} | kernarg wait before the first stamp {a[5]:.0f}", flush=True)
