@@ -263,15 +263,19 @@ __device__ __forceinline__ StepScalars step_scalars(const DevModel& m, const Dev
     StepScalars s;
     s.lam = 1.0f; s.cmx = s.cmy = s.cmz = 0.0f; s.keep = 0.0f; s.mix = 0.0f;
     if (p.kind == 0 || p.kind == 1) {
+        // hardware reciprocal / square root (1 ulp): these few scalars sit on every workgroup's critical path
+        // between the arrival of the sums and the pair loop, and the correctly rounded sequences are ~35
+        // dependent instructions each
         const float tprev = fmaxf(m.t_fac * psum.x, 1e-2f);
-        if (p.kind == 0) s.lam = sqrtf(fmaxf(fmaf(p.dt * m.fbeta, p.t_bath / tprev - 1.0f, 1.0f), 0.0f));
-        else s.lam = sqrtf(p.t_bath / tprev);
+        const float ratio = p.t_bath * __builtin_amdgcn_rcpf(tprev);
+        if (p.kind == 0) s.lam = __builtin_amdgcn_sqrtf(fmaxf(fmaf(p.dt * m.fbeta, ratio - 1.0f, 1.0f), 0.0f));
+        else s.lam = __builtin_amdgcn_sqrtf(ratio);
         s.cmx = psum.y * m.inv_n; s.cmy = psum.z * m.inv_n; s.cmz = psum.w * m.inv_n;
     } else if (p.kind == 2 || p.kind == 3) {
         // FIRE (Bitzek et al. 2006) with the power test on the previous step's sums
         if (psum.x > 0.0f) {
             s.keep = 1.0f - st.alpha;
-            s.mix = st.alpha * sqrtf(psum.z / fmaxf(psum.y, 1e-30f));
+            s.mix = st.alpha * __builtin_amdgcn_sqrtf(psum.z * __builtin_amdgcn_rcpf(fmaxf(psum.y, 1e-30f)));
             if (st.npos > fp.n_min) {
                 st.dt = fminf(st.dt * fp.f_inc, fp.dt_max);
                 st.alpha *= fp.f_alpha;
