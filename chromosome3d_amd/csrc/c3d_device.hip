@@ -72,6 +72,8 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     {   // The 244-byte kernarg block spans four 64-byte lines and the scalar cache is cold at every launch: the
         // compiler fetches the arguments where they are first used, one ~550-cycle miss after the other.  Touch
         // the three lines beyond the preloaded pointers at once; the later loads then hit.
+        static_assert(10 * sizeof(void*) + sizeof(DevModel) + sizeof(DevStep) + sizeof(DevFire) >= 0xc0 + 4,
+                      "the touched offsets must lie inside the explicit kernel arguments");
         const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
         unsigned t0, t1, t2;
         asm volatile("s_load_dword %0, %3, 0x40\n\ts_load_dword %1, %3, 0x80\n\ts_load_dword %2, %3, 0xc0\n\ts_waitcnt lgkmcnt(0)"
