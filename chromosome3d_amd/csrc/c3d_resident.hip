@@ -17,7 +17,7 @@
 // record it overwrites (step s-1) was read by all tiles before they could publish step s.
 // The arithmetic is c3d_step_core.h, the same functions in the same order as k_step: a resident range and the
 // same range run step by step give bit-identical coordinates (tests/test_gpu_parity.py).
-// Every spin is bounded: a tile that waits ~2 s sets *timeout and leaves; the host turns that into an error.
+// Every spin is bounded: a tile that waits ~0.3 s sets *timeout and leaves; the host then runs the same steps on the per-step path.
 #include "c3d_step_core.h"
 
 namespace c3d {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 5) void k_anneal(
 #endif
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 21)) {         // ~2 s: the tiles of this replica are not all resident
+                if (++spins > (1u << 18)) {         // ~0.3 s: the tiles of this replica are not all resident
                     if (lane == 0) atomicOr(timeout, 1u);
                     return;
                 }

@@ -63,6 +63,7 @@ for phase in ("idle", "loaded"):
             x, (ms, steps, launches) = anneal(s, IF, 1, 0)
             if launches > 100:
                 fallbacks += 1          # too large for the resident kernel, or it fell back
+                print(f"  {phase} round {r}: {cid} (N={IF.shape[0]}) ran step by step", flush=True)
             checked += 1
             if not np.array_equal(x, ref[cid]):
                 mism += 1
