@@ -1,12 +1,12 @@
 // c3d_api.cpp — C-ABI host of libc3d.so: context, device buffers, schedule -> launch program,
 // hipGraph replay, resident launches, timing.  Compiled with hipcc (-x hip) for the HIP runtime API only;
-// the kernels live in c3d_device.hip (per-step), c3d_resident.hip (multi-step), c3d_embed.hip, c3d_score.hip.
+// the kernels live in c3d_device.hip (per-step), c3d_cluster.hip (multi-step), c3d_embed.hip, c3d_score.hip.
 //
 // Reference boundary: chromosome3D.pl:254-289 (build_models: `cns_solve < dgsa.inp`) and the
 // deck it writes (:882-1846).  What CNS does per model (deck :1574-1829) becomes a flat
-// "program" of SA steps; a range of it runs either as one launch per step (two replica groups on two
-// streams, replayed from hipGraphs) or as ONE resident launch (run_resident), whichever is faster for
-// the problem size.  Every copy and memset is ordered on the context's own stream: contexts of different
+// "program" of SA steps; a range of it runs as ONE cluster launch (run_cluster, c3d_cluster.hip) where the
+// replicas fit the chip's XCDs, else as one launch per step (two replica groups on two streams, replayed
+// from hipGraphs).  Every copy and memset is ordered on the context's own stream: contexts of different
 // host threads never meet on the legacy stream.
 #include <hip/hip_runtime.h>
 
@@ -100,7 +100,7 @@ struct c3d_ctx {
     int rpw = 2;
     int stage_dma = 1;
     int graph_chunk = 256;
-    int resident = -1;                     // resident multi-step kernel (c3d_resident.hip): 1 on, 0 off, -1 where it is faster
+    int resident = -1;                     // multi-step cluster kernel (c3d_cluster.hip): 1 forced, 0 off, -1 where it applies
     int resident_min_ops = 4;              // shorter ranges go step by step
 
     std::vector<int32_t> h_dist10;   // n*n, from K1 (empty when restraints came from a tbl)
@@ -115,18 +115,33 @@ struct c3d_ctx {
     long steps_done = 0;
     std::map<std::tuple<long, int, int, int>, hipGraphExec_t> graphs;
 
-    // resident kernel state: device copy of the program's step parameters, the two pointer blocks (by
-    // parity), the tile-record hand-off area and the timeout word
-    c3d::StepRun* d_runs = nullptr;        // run-length coded step parameters of the launch in flight
-    size_t runs_cap = 0;
-    c3d::AnnealIO* d_io = nullptr;         // [2]
-    void* d_rec = nullptr;
-    size_t rec_bytes = 0;
-    unsigned* d_tmo = nullptr;
+    c3d::AnnealIO* d_io = nullptr;         // [2] pointer blocks of the multi-step launch, by parity
     bool inject_timeout = false;           // test hook: pretend the next resident launch timed out
     int resident_fallbacks = 0;            // resident launches abandoned for the per-step path (see run_resident)
-    int resident_cap = -1;                 // workgroups per CU of the resident kernel (-1: not queried)
+    int resident_skip = 0;                 // ranges left to run step by step before a multi-step launch is tried again
+    int resident_backoff = 0;              // doubles with every abandoned launch, back to 0 after a good one
     int num_cus = 0;
+
+    // cluster kernel state (c3d_cluster.hip): the run-length coded program on the device, op -> (run, offset),
+    // hand-off records, per-launch slot counters, the host-mapped word a workgroup that gives up writes
+    int cluster = -1;                      // 1 / -1: use it where it applies, 0: never
+    bool cl_ok = false;
+    c3d::ClusterPlan cl_plan{};
+    void* d_crec = nullptr;
+    size_t crec_bytes = 0;
+    static constexpr unsigned kClaimSets = 4096;
+    unsigned* d_claim = nullptr;           // [kClaimSets][8]
+    unsigned cl_seq = 0;
+    c3d::StepRun* d_prog = nullptr;
+    size_t prog_cap = 0;
+    bool prog_dirty = true;
+    std::vector<int> op_run, op_skip;
+    std::vector<c3d::StepRun> prog_runs;
+    unsigned* h_tmo = nullptr;             // hipHostMalloc'ed, mapped
+    unsigned* h_tmo_dev = nullptr;         // its device address
+
+    long graph_captures = 0, graph_launches = 0, step_launches = 0, resident_launches = 0, cluster_launches = 0;
+    int last_path = 0;                     // 0 per-step, 1 k_anneal, 2 k_cluster (what the last run_ops used)
 
     double last_ms = 0;
     long last_steps = 0, last_launches = 0;
@@ -145,9 +160,10 @@ void free_replica_buffers(c3d_ctx* c) {
         c->buf.X[k] = c->buf.V[k] = c->buf.P[k] = nullptr;
         c->buf.S[k] = nullptr;
     }
-    if (c->d_rec) hipFree(c->d_rec);
-    if (c->d_io) hipFree(c->d_io);
-    c->d_rec = nullptr; c->d_io = nullptr; c->rec_bytes = 0;
+    if (c->d_io) (void)hipFree(c->d_io);
+    if (c->d_crec) (void)hipFree(c->d_crec);
+    c->d_io = nullptr;
+    c->d_crec = nullptr; c->crec_bytes = 0; c->cl_ok = false;
     if (c->buf.Vinit) hipFree(c->buf.Vinit);
     if (c->buf.E) hipFree(c->buf.E);
     if (c->d_feval) hipFree(c->d_feval);
@@ -217,8 +233,19 @@ void build_program(c3d_ctx* c) {
         prev_kind = st.kind;
     }
     c->pc = 0;
-    c->resident_cap = -1;
     drop_graphs(c);
+    // run-length code of the whole program (a FIRE stage is 2 runs, the cool ramp 81) for the cluster kernel
+    c->prog_runs.clear();
+    c->op_run.assign(c->program.size(), 0);
+    c->op_skip.assign(c->program.size(), 0);
+    for (size_t k = 0; k < c->program.size(); ++k) {
+        const c3d::DevStep& p = c->program[k].p;
+        if (!c->prog_runs.empty() && memcmp(&c->prog_runs.back().p, &p, sizeof(p)) == 0) ++c->prog_runs.back().count;
+        else c->prog_runs.push_back({p, 1});
+        c->op_run[k] = (int)c->prog_runs.size() - 1;
+        c->op_skip[k] = c->prog_runs.back().count - 1;
+    }
+    c->prog_dirty = true;
 }
 
 int upload_targets(c3d_ctx* c, const std::vector<float>& enc) {
@@ -273,123 +300,142 @@ int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
     return C3D_OK;
 }
 
-// Can the ops run as one resident launch?  The model must fit the kernel (npad <= 1024) and every workgroup
-// (replica x tile) must be resident at once.
-bool resident_ok(c3d_ctx* c) {
-    if (!c->resident || !c->d_rec) return false;
-    const c3d::DevModel m = dev_model(c);
-    if (!c3d::anneal_supported(m)) return false;
-    // measured on MI355X (profiles/r01_resident_crossover.txt): the resident kernel wins while its waves
-    // (4 per workgroup) stay below ~2.9 per SIMD, the per-step graph path above that
-    if (c->resident < 0 && (long)c->nrep * c->ntiles * 4 > (long)(2.9 * 4 * c->num_cus)) return false;
-    if (c->resident_cap < 0) {
-        int cap = 0;
-        if (c3d::anneal_blocks_per_cu(m, general_tail(m), &cap) != hipSuccess) cap = 0;
-        c->resident_cap = cap;
-    }
-    return (long)c->nrep * c->ntiles <= (long)c->resident_cap * c->num_cus;
+// Can the ops run as one k_cluster launch (a replica on a few 1024-thread workgroups of one XCD)?
+bool cluster_ok(c3d_ctx* c) {
+    if (!c->resident || !c->cluster || !c->cl_ok || !c->d_crec) return false;
+    return !general_tail(dev_model(c));
 }
 
-int run_resident(c3d_ctx* c, size_t nops, bool* ran) {
-    // consecutive ops with identical parameters become one run (a FIRE stage is 2 runs, the cool ramp 81)
-    std::vector<c3d::StepRun> runs;
-    for (size_t k = 0; k < nops; ++k) {
-        const c3d::DevStep& p = c->program[c->pc + k].p;
-        if (!runs.empty() && memcmp(&runs.back().p, &p, sizeof(p)) == 0) ++runs.back().count;
-        else runs.push_back({p, 1});
-    }
-    if (runs.size() > c->runs_cap) {
-        if (c->d_runs) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_runs); c->d_runs = nullptr; }
-        c->runs_cap = std::max<size_t>(runs.size(), 256);
-        HIP_TRY(hipMalloc(&c->d_runs, sizeof(c3d::StepRun) * c->runs_cap));
-    }
-    // stream-ordered after the previous launch (pageable source: the call returns once the data is staged)
-    HIP_TRY(hipMemcpyAsync(c->d_runs, runs.data(), sizeof(c3d::StepRun) * runs.size(), hipMemcpyHostToDevice, c->stream));
-    const c3d::DevModel m = dev_model(c);
-    HIP_TRY(hipMemsetAsync(c->d_rec, 0, c->rec_bytes, c->stream));
-    if (c->inject_timeout) {
-        const unsigned one = 1;
-        HIP_TRY(hipMemcpyAsync(c->d_tmo, &one, sizeof(one), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->inject_timeout = false;
-    }
-    hipError_t e = c3d::launch_anneal(m, dev_fire(c), c->d_io + c->parity, c->buf.tgt, general_tail(m), c->d_rec,
-                                      c->d_runs, (int)runs.size(), (int)nops, c->d_tmo, c->stream);
-    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("resident launch: ") + hipGetErrorString(e));
-    // The launch reads parity p and writes parity p^1 only in its last step, so its inputs are intact whatever
-    // happens: if a tile gave up waiting (its replica's workgroups were not all resident, e.g. another process
-    // fills the GPU), switch this context to the per-step path and let the caller run the same ops there.
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    unsigned t = 0;
-    HIP_TRY(hipMemcpyAsync(&t, c->d_tmo, sizeof(t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (t) {
-        HIP_TRY(hipMemsetAsync(c->d_tmo, 0, sizeof(t), c->stream));
-        c->resident = 0;
-        ++c->resident_fallbacks;
-        *ran = false;
-        return C3D_OK;
-    }
-    *ran = true;
+// after a multi-step launch: did a workgroup give up (or was that injected)?  The launch reads parity p and writes
+// parity p^1 only in its last step, so its inputs are intact whatever happened: if a workgroup gave up waiting (its
+// replica's workgroups were not all resident, e.g. another process fills the GPU) the caller runs the same ops on
+// the per-step path; the next `resident_backoff` ranges go there too before a multi-step launch is tried again.
+bool launch_was_abandoned(c3d_ctx* c) {
+    if (!*c->h_tmo) { c->resident_backoff = 0; return false; }
+    *c->h_tmo = 0;
+    c->resident_backoff = std::min(4096, std::max(4, 2 * c->resident_backoff));
+    c->resident_skip = c->resident_backoff;
+    ++c->resident_fallbacks;
+    return true;
+}
+void account_ops(c3d_ctx* c, size_t nops) {
     c->parity ^= 1;
     for (size_t k = 0; k < nops; ++k)
         if (c->program[c->pc + k].counted) { ++c->steps_done; ++c->last_steps; }
     c->last_launches += 1;
     c->pc += nops;
+}
+
+int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
+    if (c->prog_dirty) {
+        if (c->prog_runs.size() > c->prog_cap) {
+            if (c->d_prog) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_prog); c->d_prog = nullptr; }
+            c->prog_cap = std::max<size_t>(c->prog_runs.size(), 256);
+            HIP_TRY(hipMalloc(&c->d_prog, sizeof(c3d::StepRun) * c->prog_cap));
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_prog, c->prog_runs.data(), sizeof(c3d::StepRun) * c->prog_runs.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->prog_dirty = false;
+    }
+    // tags of a launch carry its sequence number; records and slot counters are wiped when the number wraps
+    const unsigned seq = c->cl_seq % c3d_ctx::kClaimSets;
+    if (seq == 0) {
+        HIP_TRY(hipMemsetAsync(c->d_crec, 0, c->crec_bytes, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_claim, 0, sizeof(unsigned) * 8 * c3d_ctx::kClaimSets, c->stream));
+    }
+    ++c->cl_seq;
+    if (c->inject_timeout) { *c->h_tmo = 1; c->inject_timeout = false; }
+    const c3d::DevModel m = dev_model(c);
+    hipError_t e = c3d::launch_cluster(m, dev_fire(c), c->cl_plan, c->d_io + c->parity, c->buf.tgt, c->d_crec, c->d_prog,
+                                       c->op_run[c->pc], c->op_skip[c->pc], (int)nops, seq << 20, c->h_tmo_dev,
+                                       c->d_claim + 8 * seq, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("cluster launch: ") + hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ++c->cluster_launches;
+    if (launch_was_abandoned(c)) { *ran = false; return C3D_OK; }
+    *ran = true;
+    c->last_path = 2;
+    account_ops(c, nops);
     return C3D_OK;
 }
 
 // run program ops [pc, pc + nops): eager or via cached graphs; every replica group advances on its
 // own stream (fork from / join into stream 0 around the call)
 int run_ops(c3d_ctx* c, size_t nops) {
-    if (nops >= (size_t)c->resident_min_ops && nops < (size_t)INT32_MAX && resident_ok(c)) {
+    if (nops == 0) return C3D_OK;
+    if (c->resident_skip > 0 && c->resident < 1) --c->resident_skip;     // cooling off after an abandoned launch
+    else if (nops >= (size_t)c->resident_min_ops && nops < ((size_t)1 << 20)) {
         bool ran = false;
-        const int rc = run_resident(c, nops, &ran);
+        int rc = C3D_OK;
+        if (cluster_ok(c)) rc = run_cluster(c, nops, &ran);
         if (rc != C3D_OK || ran) return rc;
     }
+    c->last_path = 0;
     const int G = active_groups(c);
-    if (G > 1) {
-        HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
-        for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(c->gstream[g], c->fork_ev, 0));
-    }
+    // eager: every replica group advances on its own stream (fork from / join into stream 0 around the range)
+    auto fork = [&]() -> int {
+        if (G > 1) {
+            HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
+            for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(c->gstream[g], c->fork_ev, 0));
+        }
+        return C3D_OK;
+    };
+    auto join = [&]() -> int {
+        for (int g = 1; g < G; ++g) {
+            HIP_TRY(hipEventRecord(c->gev[g], c->gstream[g]));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->gev[g], 0));
+        }
+        return C3D_OK;
+    };
+    auto launch_chunk = [&](size_t chunk) -> int {
+        for (int g = 0; g < G; ++g) {
+            int par = c->parity;
+            for (size_t k = 0; k < chunk; ++k) {
+                int rc = launch_op(c, c->program[c->pc + k], g, par);
+                if (rc) return rc;
+                par ^= 1;
+            }
+        }
+        c->step_launches += (long)chunk * G;
+        return C3D_OK;
+    };
     size_t done = 0;
     while (done < nops) {
         const size_t chunk = std::min<size_t>(nops - done, c->use_graph ? (size_t)c->graph_chunk : nops - done);
-        if (!c->use_graph || chunk < 8) {
-            for (int g = 0; g < G; ++g) {
-                int par = c->parity;
-                for (size_t k = 0; k < chunk; ++k) {
-                    int rc = launch_op(c, c->program[c->pc + k], g, par);
-                    if (rc) return rc;
-                    par ^= 1;
-                }
-            }
+        int rc;
+        if (!c->use_graph || chunk < 4) {
+            if ((rc = fork()) || (rc = launch_chunk(chunk)) || (rc = join())) return rc;
         } else {
-            // homogeneous FIRE ranges (same stage, all kind 2) share one graph regardless of pc
+            // ONE graph holds the chunk of every replica group (the groups are parallel branches of it): one
+            // hipGraphLaunch per chunk.  Homogeneous FIRE ranges (same stage, all kind 2) share a graph regardless of pc.
             const Op& first = c->program[c->pc];
             const Op& last = c->program[c->pc + chunk - 1];
             long sig = (long)c->pc;
             if (first.p.kind == 2 && last.p.kind == 2 && first.stage == last.stage) sig = -(long)(first.stage + 1);
-            for (int g = 0; g < G; ++g) {
-                const auto key = std::make_tuple(sig, (int)chunk, c->parity, g);
-                auto it = c->graphs.find(key);
-                if (it == c->graphs.end()) {
-                    hipGraph_t gr = nullptr;
-                    HIP_TRY(hipStreamBeginCapture(c->gstream[g], hipStreamCaptureModeThreadLocal));
-                    int par = c->parity;
-                    int rc = C3D_OK;
-                    for (size_t k = 0; k < chunk && rc == C3D_OK; ++k) { rc = launch_op(c, c->program[c->pc + k], g, par); par ^= 1; }
-                    hipError_t ce = hipStreamEndCapture(c->gstream[g], &gr);
-                    if (rc) { if (gr) hipGraphDestroy(gr); return rc; }
-                    if (ce != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-                    hipGraphExec_t ge = nullptr;
-                    hipError_t ie = hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0);
-                    hipGraphDestroy(gr);
-                    if (ie != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
-                    it = c->graphs.emplace(key, ge).first;
-                }
-                HIP_TRY(hipGraphLaunch(it->second, c->gstream[g]));
+            const auto key = std::make_tuple(sig, (int)chunk, c->parity, G);
+            auto it = c->graphs.find(key);
+            if (it == c->graphs.end()) {
+                if (c->graphs.size() >= 1024) drop_graphs(c);      // bounded: a caller with ever new ranges starts over
+                hipGraph_t gr = nullptr;
+                HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                rc = fork();
+                const long before = c->step_launches;
+                if (!rc) rc = launch_chunk(chunk);
+                c->step_launches = before;                           // captured, not launched
+                if (!rc) rc = join();
+                hipError_t ce = hipStreamEndCapture(c->stream, &gr);
+                if (rc) { if (gr) hipGraphDestroy(gr); return rc; }
+                if (ce != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+                hipGraphExec_t ge = nullptr;
+                hipError_t ie = hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0);
+                hipGraphDestroy(gr);
+                if (ie != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+                it = c->graphs.emplace(key, ge).first;
+                ++c->graph_captures;
             }
+            HIP_TRY(hipGraphLaunch(it->second, c->stream));
+            ++c->graph_launches;
+            c->step_launches += (long)chunk * G;
         }
         if (chunk & 1) c->parity ^= 1;
         for (size_t k = 0; k < chunk; ++k)
@@ -397,10 +443,6 @@ int run_ops(c3d_ctx* c, size_t nops) {
         c->last_launches += (long)chunk;
         c->pc += chunk;
         done += chunk;
-    }
-    for (int g = 1; g < G; ++g) {
-        HIP_TRY(hipEventRecord(c->gev[g], c->gstream[g]));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->gev[g], 0));
     }
     return C3D_OK;
 }
@@ -523,8 +565,13 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     for (int g = 1; ok && g < c3d_ctx::kMaxGroups; ++g)
         ok = hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipMalloc(&c->d_tmo, 16) == hipSuccess && hipMemsetAsync(c->d_tmo, 0, 16, c->stream) == hipSuccess &&
-         hipStreamSynchronize(c->stream) == hipSuccess;
+    // the word a multi-step launch sets when a workgroup gives up: host memory, read after the stream has drained
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_tmo), 64, hipHostMallocMapped) == hipSuccess;
+    if (ok) {
+        *c->h_tmo = 0;
+        ok = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_tmo_dev), c->h_tmo, 0) == hipSuccess &&
+             hipMalloc(&c->d_claim, sizeof(unsigned) * 8 * c3d_ctx::kClaimSets) == hipSuccess;
+    }
     if (!ok) {
         c3d_destroy(c);
         return fail(C3D_ERR_HIP, "cannot create HIP stream/events");
@@ -540,8 +587,9 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
     drop_graphs(c);
     free_replica_buffers(c);
     if (c->buf.tgt) hipFree(c->buf.tgt);
-    if (c->d_runs) hipFree(c->d_runs);
-    if (c->d_tmo) hipFree(c->d_tmo);
+    if (c->d_prog) (void)hipFree(c->d_prog);
+    if (c->d_claim) (void)hipFree(c->d_claim);
+    if (c->h_tmo) (void)hipHostFree(c->h_tmo);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (int g = 1; g < c3d_ctx::kMaxGroups; ++g) {
@@ -592,7 +640,8 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         drop_graphs(c);
         return C3D_OK;
     }
-    if (!strcmp(key, "resident")) { c->resident = value < 0 ? -1 : (value != 0); return C3D_OK; }
+    if (!strcmp(key, "resident")) { c->resident = value < 0 ? -1 : (value != 0); c->resident_skip = 0; return C3D_OK; }
+    if (!strcmp(key, "cluster")) { c->cluster = value < 0 ? -1 : (value != 0); return C3D_OK; }
     if (!strcmp(key, "resident_inject_timeout")) { c->inject_timeout = value != 0; return C3D_OK; }   // test hook
     if (!strcmp(key, "resident_min_ops")) { c->resident_min_ops = value < 1 ? 1 : (int)value; return C3D_OK; }
     if (!strcmp(key, "stage_dma")) { c->stage_dma = value != 0; drop_graphs(c); return C3D_OK; }
@@ -694,16 +743,21 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
         HIP_TRY(hipMalloc(&c->buf.Vinit, sizeof(float) * nf));
         HIP_TRY(hipMalloc(&c->buf.E, sizeof(double) * 4 * nrep));
         HIP_TRY(hipMalloc(&c->d_feval, sizeof(float) * nf));
-        // resident kernel: hand-off records and the two pointer blocks (one per step parity)
+        // cluster kernel: the two pointer blocks (one per step parity), geometry for this (n, replicas), records
         {
             c3d::DevModel m = dev_model(c);
-            m.nrep = nrep;
-            c->rec_bytes = c3d::anneal_record_bytes(m);
-            HIP_TRY(hipMalloc(&c->d_rec, c->rec_bytes));
+            m.nrep = nrep; m.nrep_g = nrep; m.rep_base = 0;
             const c3d::AnnealIO io[2] = {c3d::anneal_io(c->buf, 0), c3d::anneal_io(c->buf, 1)};
             HIP_TRY(hipMalloc(&c->d_io, sizeof(io)));
             HIP_TRY(hipMemcpyAsync(c->d_io, io, sizeof(io), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            c->cl_ok = c3d::cluster_plan(m, c->num_cus, &c->cl_plan);
+            if (c->cl_ok) {
+                c->cl_plan.device = c->device;
+                c->crec_bytes = c3d::cluster_record_bytes(m, c->cl_plan);
+                HIP_TRY(hipMalloc(&c->d_crec, c->crec_bytes));
+                c->cl_seq = 0;                     // the first launch wipes the records and the slot counters
+            }
         }
         c->have_replicas = true;
     }
@@ -906,6 +960,36 @@ extern "C" int c3d_last_timing(const c3d_ctx* c, double* ms_total, long* steps, 
     return C3D_OK;
 }
 
+extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
+    if (!c || !key || !value) return fail(C3D_ERR_INVALID, "c3d_get_stat: null argument");
+    if (!strcmp(key, "graph_captures")) *value = (double)c->graph_captures;
+    else if (!strcmp(key, "graph_launches")) *value = (double)c->graph_launches;
+    else if (!strcmp(key, "graphs_cached")) *value = (double)c->graphs.size();
+    else if (!strcmp(key, "step_launches")) *value = (double)c->step_launches;
+    else if (!strcmp(key, "resident_launches")) *value = (double)c->resident_launches;
+    else if (!strcmp(key, "cluster_launches")) *value = (double)c->cluster_launches;
+    else if (!strcmp(key, "resident_fallbacks")) *value = (double)c->resident_fallbacks;
+    else if (!strcmp(key, "last_path")) *value = (double)c->last_path;
+    else if (!strcmp(key, "cluster_parts")) *value = c->cl_ok ? (double)c->cl_plan.parts : 0.0;
+    else if (!strcmp(key, "cluster_rows_per_wave")) *value = c->cl_ok ? (double)c->cl_plan.rpw : 0.0;
+    else if (!strcmp(key, "cluster_compute_waves")) *value = c->cl_ok ? (double)c->cl_plan.cw : 0.0;
+    else if (!strcmp(key, "replica_groups")) *value = (double)active_groups(c);
+    else return fail(C3D_ERR_INVALID, std::string("c3d_get_stat: unknown key ") + key);
+    return C3D_OK;
+}
+
+// name of the kernel the last range ran on, as rocprofv3 prints it (without the argument list)
+extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
+    static thread_local char buf[96];
+    if (!c) return "";
+    const c3d::DevModel m = dev_model(c);
+    const char* gen = general_tail(m) ? "true" : "false";
+    const char* rs1 = (!general_tail(m) && m.rs == 1.0f) ? "true" : "false";
+    if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %s>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, rs1);
+    else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d, %s>", m.noe_pot, gen, m.rpw, rs1);
+    return buf;
+}
+
 extern "C" int c3d_eval(c3d_ctx* c, float w_all, float w_vdw, float repel_s, float* F, double* e) {
     if (!c || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_eval: bad state");
     HIP_TRY(hipSetDevice(c->device));
@@ -998,9 +1082,13 @@ extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
 }
 
 #ifdef C3D_STAMPS
-namespace c3d { hipError_t read_stamps(unsigned long long* out); hipError_t read_resident_stamps(unsigned long long* out); }
-extern "C" int c3d_debug_resident_stamps(unsigned long long* out) {
-    hipError_t e = c3d::read_resident_stamps(out);
+namespace c3d { hipError_t read_stamps(unsigned long long* out); hipError_t read_cluster_stamps(unsigned long long* out); }
+namespace c3d { hipError_t read_debug_forces(float* out); hipError_t read_debug_forces_step(float* out); }
+extern "C" int c3d_debug_forces(float* out, int which) {
+    return (which ? c3d::read_debug_forces(out) : c3d::read_debug_forces_step(out)) == hipSuccess ? C3D_OK : C3D_ERR_HIP;
+}
+extern "C" int c3d_debug_cluster_stamps(unsigned long long* out) {
+    hipError_t e = c3d::read_cluster_stamps(out);
     return e == hipSuccess ? C3D_OK : C3D_ERR_HIP;
 }
 extern "C" int c3d_debug_stamps(unsigned long long* out) {

@@ -1,0 +1,398 @@
+// c3d_cluster.hip — K3/K4 as ONE launch for many SA steps: a replica on a few LARGE workgroups of ONE XCD (gfx950).
+//
+// The solver is bound by VALU issue (a wave64 instruction holds its SIMD ~4 cycles: tools/microbench/valu_rate and the
+// SQ counters in profiles/), so a step costs what its instruction count costs — and in a kernel where every wave also
+// reduces the replica sums, evaluates chain terms, updates rows and handles records, that overhead is as large as the
+// pair loop.  Here the waves of a workgroup are specialised:
+//
+//   compute waves (CW of them, RPW rows each)   pair loop with targets and NOE weights in registers, butterfly sum,
+//                                               three LDS words per row — nothing else
+//   helper H0   (lane k <-> row k of the workgroup)   replica sums -> step scalars; after the barrier: force = pair sum
+//                                               + chain sum, row update, tile sums (DPP), publishes the record
+//   helpers H1..H3   the chain terms of 16 rows each, one (row, neighbour) per lane, quad sum
+//
+// and the workgroups of a replica are few and share an XCD:
+//
+//   placement   a workgroup reads HW_REG_XCC_ID and takes a slot from THAT XCD's counter: slot -> (replica, part).
+//               Replica r lives on XCD r % 8 whatever the dispatcher did; a CU without work exits at once.
+//   hand-off    part p publishes per row two 16-byte units {tag, x, tag, y} {tag, z, tag, s} (s = one word of the
+//               8-row tile sums) with PLAIN stores: they write through the CU's L1 into the XCD's L2 and stay there;
+//               every thread gathers its units of the replica's P records with L1-bypassing (sc1) loads until the
+//               tags match.  Producer and consumers share one L2; nothing crosses the fabric.  Measured (tools/
+//               microbench/xcd_handoff.hip, 20 replicas x 10 workgroups): 0.77 us per step, against 1.65 us with
+//               write-through stores and 2.8 us for round 1's 57-records-per-replica form.
+//   P == 1      (N <= 64) a replica is one workgroup: no record at all, positions go LDS -> LDS.
+//
+// Arithmetic: c3d_step_core.h, every row's force and every sum formed in the order k_step forms it, so a range run
+// here ends in the bits of the per-step path.  Every spin is bounded; a workgroup that gives up sets *timeout and the
+// host re-runs the range step by step (the launch only writes its outputs in its last step).
+// Deck: chromosome3D.pl:1646-1700 (hot MD), :1729-1782 (cooling), :1790-1803 (minimisation).
+#include <cstdio>
+#include <cstdlib>
+
+#include "c3d_step_core.h"
+
+namespace c3d {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kClHelpers = 4;
+constexpr int kClMaxThreads = 1024;
+
+// Diagnostic build only (-DC3D_STAMPS, tools/stamps): cycles per phase of helper H0 of workgroup (replica 0, part 0),
+// summed over the steps of a launch, plus the number of gather sweeps.
+#ifdef C3D_STAMPS
+__device__ unsigned long long g_cstamps[16];
+#define CSTAMP(k)                                                                                       \
+    do {                                                                                                \
+        if (stamper) {                                                                                  \
+            const unsigned long long t_ = __builtin_readcyclecounter();                                 \
+            cacc[k] += t_ - clast;                                                                      \
+            clast = t_;                                                                                 \
+        }                                                                                               \
+    } while (0)
+#else
+#define CSTAMP(k) do { } while (0)
+#endif
+
+template <int POT, int RPW, int NB, bool RS1>
+__global__ __launch_bounds__(kClMaxThreads) void k_cluster(
+    const AnnealIO* __restrict__ io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
+    const StepRun* __restrict__ runs, const int run0, const int skip0, const int nsteps, const unsigned tag_base,
+    volatile unsigned* __restrict__ timeout, unsigned* __restrict__ claim, const int P, const int CW, const DevModel m,
+    const DevFire fp) {
+    constexpr int NPAD = 256 * NB;
+    constexpr int MAXT = NPAD / 8;
+    constexpr int KUMAX = NB > 2 ? 3 : 2;         // gather loads per thread: P * 2 RW <= threads * KUMAX
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* ys = smem + NPAD;
+    float* zs = smem + 2 * NPAD;
+    float* ps = smem + 3 * NPAD;                  // [MAXT][4] per-tile sums of the previous step
+    float* fbuf = ps + 4 * MAXT;                  // [3][64] pair sums of this workgroup's rows (compute waves -> H0)
+    float* cbuf = fbuf + 3 * 64;                  // [3][64] chain sums of this workgroup's rows (H1..H3 -> H0)
+    float* dump = cbuf + 3 * 64;                  // [4] nobody reads
+    int* s_slot = reinterpret_cast<int*>(dump + 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = (CW + kClHelpers) * 64;
+    const int RW = CW * RPW;                      // rows of one workgroup: a multiple of 8 (whole tiles), <= 64
+
+    // ---- placement: (replica, part) from this XCD's slot counter ---------------------------------
+    const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0x7);     // HW_REG_XCC_ID
+    if (tid == 0) *s_slot = (int)atomicAdd(&claim[xcc], 1u);
+    __syncthreads();
+    const int slot = *s_slot;
+    const int lrep = xcc + 8 * (slot / P), part = slot % P;       // replica index inside this launch's group
+    if (lrep >= m.nrep_g) return;                 // this CU has nothing to do
+    const int rep = m.rep_base + lrep;
+    const bool solo = P == 1;
+    const bool is_compute = wave < CW, is_h0 = wave == CW;
+
+    const size_t roff = (size_t)rep * 3 * NPAD;
+    const int wg_row0 = part * RW;
+    const int row0 = wg_row0 + wave * RPW;        // compute waves: first row of the wave
+    const int hrow = wg_row0 + lane;              // H0: the row of this lane
+    const bool hfin = is_h0 && lane < RW && hrow < m.n;
+#define C3D_HROW_INDEX const size_t ix = roff + hrow, iy = ix + NPAD, iz = iy + NPAD   /* formed where used: H0 only */
+    const int units = P * 2 * RW;
+    const int ku = (units + nthreads - 1) / nthreads;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, (int)(sizeof(u32x4) * 2 * m.nrep_g * units), 0x00020000);
+
+    // ---- prologue: everything that stays for the whole launch --------------------------------------
+    float4 tv[RPW][NB];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+            tv[r][jb] = is_compute ? *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * NPAD + 256 * jb + 4 * lane)
+                                   : make_float4(0, 0, 0, 0);
+    float vcx = 0.0f, vcy = 0.0f, vcz = 0.0f;     // H0: velocity of this lane's row, carried from step to step
+    FireState st;
+    {
+        const float* xin = io->xin;
+        const float* pin = io->pin;
+        const float* vin = io->vin;
+        for (int b = 4 * tid; b < 3 * NPAD; b += 4 * nthreads)
+            *reinterpret_cast<float4*>(smem + b) = *reinterpret_cast<const float4*>(xin + roff + b);
+        for (int t = tid; t < m.ntiles; t += nthreads)
+            reinterpret_cast<float4*>(ps)[t] = reinterpret_cast<const float4*>(pin)[(size_t)rep * m.ntiles + t];
+        if (hfin) { C3D_HROW_INDEX; vcx = vin[ix]; vcy = vin[iy]; vcz = vin[iz]; }
+        st = io->sin[rep];
+    }
+    // gather bookkeeping: unit u = tid + nthreads k is unit (u & 1) of row (u >> 1) % RW of part (u >> 1) / RW:
+    // unit 0 = {x, y}, unit 1 = {z, s}; s = word (row & 7) of the tile's four sums where row & 7 < 4
+    int gda[KUMAX], gdb[KUMAX];                   // float offsets into smem
+    const int dump_off = (int)(dump - smem);
+#pragma unroll
+    for (int k = 0; k < KUMAX; ++k) {
+        const int u = tid + nthreads * k;
+        int da = dump_off, db = dump_off;
+        if (u < units) {
+            const int r = u >> 1;                 // part * RW + row in part = global row
+            if (r < NPAD) {
+                if ((u & 1) == 0) { da = r; db = NPAD + r; }
+                else {
+                    da = 2 * NPAD + r;
+                    if ((r & 7) < 4) db = 3 * NPAD + 4 * (r >> 3) + (r & 7);
+                }
+            }
+        }
+        gda[k] = da; gdb[k] = db;
+    }
+
+#ifdef C3D_STAMPS
+    const bool stamper = lrep == 0 && part == 0 && is_h0 && lane == 0;
+    unsigned long long cacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clast = __builtin_readcyclecounter();
+#endif
+    int s = 0;
+    for (int run = run0;; ++run) {                  // left by the `return` of the last step
+      const DevStep p = runs[run].p;
+      const int count = runs[run].count;
+      const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
+      float4 mw[RPW][NB];                           // NOE weight of every pair of this wave for this run: -2 w S or 0
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) mw[r][jb] = noe_weights(p, tv[r][jb]);
+      for (int it = run == run0 ? skip0 : 0; it < count; ++it, ++s) {
+        CSTAMP(0);                                  // LDS writes of the gather / loop bookkeeping
+        __syncthreads();                            // B1: xs/ys/zs/ps of this step are in LDS
+        CSTAMP(1);                                  // barrier wait
+
+        StepScalars sc;
+        sc.lam = 1.0f; sc.cmx = sc.cmy = sc.cmz = 0.0f; sc.keep = 0.0f; sc.mix = 0.0f;
+        if (is_compute) {
+            // ---- K2: pair terms of RPW rows, butterfly sums, three words per row for H0 ------------------
+            if (p.kind != 4) {
+                float Fx, Fy, Fz;
+                tile_pair_sums_reg<POT, RPW, NB, true, RS1>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
+                if (lane < RPW) {
+                    const int k = wave * RPW + lane;
+                    fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz;
+                }
+            }
+        } else if (is_h0) {
+            // ---- replica sums of the previous step -> scalars of this one (only H0 needs them) -----------
+            if (p.kind != 2) { st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0; }
+            float4 psum = make_float4(0, 0, 0, 0);
+            if (needs_partials) {
+                for (int t = lane; t < m.ntiles; t += 64) {
+                    const float4 q = reinterpret_cast<const float4*>(ps)[t];
+                    psum.x += q.x; psum.y += q.y; psum.z += q.z; psum.w += q.w;
+                }
+                psum = wave_sum4(psum);
+                // the butterfly's association differs from quad to quad: every row takes lane 0's sums (the per-step kernel's
+                // finisher lanes sit in quad 0)
+                psum.x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(psum.x)));
+                psum.y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(psum.y)));
+                psum.z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(psum.z)));
+                psum.w = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(psum.w)));
+            }
+            sc = step_scalars(m, p, fp, psum, st);
+            CSTAMP(2);                              // sums + scalars
+        } else if (p.kind != 4) {
+            // ---- chain terms: lane = (row, neighbour), 16 rows per helper and pass ------------------------
+            for (int cb = 16 * (wave - CW - 1); cb < RW; cb += 16 * (kClHelpers - 1)) {
+                const int k = cb + (lane >> 2);
+                float cx, cy, cz;
+                chain_term(m, p, xs, ys, zs, wg_row0 + k, lane & 3, k < RW, cx, cy, cz);
+                cx = quad_chain_sum(cx); cy = quad_chain_sum(cy); cz = quad_chain_sum(cz);
+                if ((lane & 3) == 0 && k < RW) { cbuf[k] = cx; cbuf[64 + k] = cy; cbuf[128 + k] = cz; }
+            }
+        }
+        __syncthreads();                            // B2: all LDS reads of this step are done; fbuf / cbuf complete
+        CSTAMP(3);                                  // wait for the compute waves
+        const bool last = s + 1 == nsteps;
+        const unsigned tag = tag_base + (unsigned)s + 1u;
+        const int base = (((s + 1) & 1) * m.nrep_g + lrep) * units;
+
+        if (is_h0) {
+            // ---- row update, lane k <-> row k of the workgroup ------------------------------------------
+            float4 q = make_float4(0, 0, 0, 0);
+            float xn = 0.0f, yn = 0.0f, zn = 0.0f;
+            if (hfin) {
+                float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
+                if (p.kind != 4) { Fx = fbuf[lane] + cbuf[lane]; Fy = fbuf[64 + lane] + cbuf[64 + lane]; Fz = fbuf[128 + lane] + cbuf[128 + lane]; }
+#ifdef C3D_STAMPS
+                if (rep == 0 && p.kind != 4 && hrow < 1024)
+                    for (int c = 0; c < 3; ++c) { g_dbgF[1][c][hrow] = fbuf[64 * c + lane]; g_dbgF[1][3 + c][hrow] = cbuf[64 * c + lane]; }
+#endif
+                float vx0 = vcx, vy0 = vcy, vz0 = vcz;
+                if (p.kind == 3) { vx0 = vy0 = vz0 = 0.0f; }
+                else if (p.kind == 4) { C3D_HROW_INDEX; const float* vinit = io->vinit; vx0 = vinit[ix]; vy0 = vinit[iy]; vz0 = vinit[iz]; }
+                finish_row(m, p, fp, sc, st, Fx, Fy, Fz, xs[hrow], ys[hrow], zs[hrow], vx0, vy0, vz0, xn, yn, zn, vcx, vcy, vcz, q);
+            } else if (lane < RW && hrow < NPAD) {
+                xn = xs[hrow]; yn = ys[hrow]; zn = zs[hrow];    // padding row: republish as is
+            }
+            // tile sums, the tree of tile_sum8 over eight consecutive lanes: lane 8 t ends with tile t's four sums
+            float4 t = q;
+            t.x += dpp_mov<0xB1>(t.x); t.y += dpp_mov<0xB1>(t.y); t.z += dpp_mov<0xB1>(t.z); t.w += dpp_mov<0xB1>(t.w);
+            t.x += dpp_mov<0x4E>(t.x); t.y += dpp_mov<0x4E>(t.y); t.z += dpp_mov<0x4E>(t.z); t.w += dpp_mov<0x4E>(t.w);
+            t.x += dpp_mov<0x12C>(t.x); t.y += dpp_mov<0x12C>(t.y); t.z += dpp_mov<0x12C>(t.z); t.w += dpp_mov<0x12C>(t.w);   // row_ror:12 = lane + 4
+            CSTAMP(4);                              // row update
+            if (last) {                             // hand the state back to the ordinary buffers
+                if (hfin) {
+                    C3D_HROW_INDEX;
+                    float* xout = io->xout;
+                    float* vout = io->vout;
+                    xout[ix] = xn; xout[iy] = yn; xout[iz] = zn;
+                    vout[ix] = vcx; vout[iy] = vcy; vout[iz] = vcz;
+                }
+                const int tl = (wg_row0 + lane) >> 3;
+                if ((lane & 7) == 0 && lane < RW && tl < m.ntiles) reinterpret_cast<float4*>(io->pout)[(size_t)rep * m.ntiles + tl] = t;
+                if (lane == 0 && part == 0) io->sout[rep] = st;
+            } else if (solo) {
+                // one workgroup owns the replica: new positions and tile sums go straight back into LDS
+                if (lane < RW && hrow < NPAD) { xs[hrow] = xn; ys[hrow] = yn; zs[hrow] = zn; }
+                if ((lane & 7) == 0 && lane < RW) reinterpret_cast<float4*>(ps)[lane >> 3] = t;
+            } else if (lane < RW) {
+                // publish: word (lane & 7) of the tile's sums rides with rows 8 t .. 8 t + 3
+                const float s1 = dpp_mov<0x111>(t.y), s2 = dpp_mov<0x112>(t.z), s3 = dpp_mov<0x113>(t.w);   // row_shr:1..3
+                const int c = lane & 7;
+                const float sw = c == 0 ? t.x : (c == 1 ? s1 : (c == 2 ? s2 : (c == 3 ? s3 : 0.0f)));
+                u32x4 o0, o1;
+                o0.x = tag; o0.y = __float_as_uint(xn); o0.z = tag; o0.w = __float_as_uint(yn);
+                o1.x = tag; o1.y = __float_as_uint(zn); o1.z = tag; o1.w = __float_as_uint(sw);
+                const int u0 = base + 2 * (part * RW + lane);
+                __builtin_amdgcn_raw_buffer_store_b128(o0, rsrc, u0 * 16, 0, 0);          // plain: the line stays in this XCD's L2
+                __builtin_amdgcn_raw_buffer_store_b128(o1, rsrc, (u0 + 1) * 16, 0, 0);
+            }
+        }
+#ifdef C3D_STAMPS
+        if (last && stamper) for (int k = 0; k < 10; ++k) g_cstamps[k] = cacc[k];
+#endif
+        if (last) return;
+        if (solo) continue;
+        CSTAMP(6);                                  // publish
+        // ---- gather the replica's records of step s+1 into LDS: re-read until every tag matches ----------
+        {
+            u32x4 v[KUMAX];
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                asm volatile("" ::: "memory");     // the loads below must be re-issued on every sweep
+#pragma unroll
+                for (int k = 0; k < KUMAX; ++k)
+                    if (k < ku) {
+                        const int u = min(tid + nthreads * k, units - 1);
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + u) * 16, 0, 16);   // aux 16 = sc1: bypass L1
+                    }
+#pragma unroll
+                for (int k = 0; k < KUMAX; ++k)
+                    if (k < ku) ok &= v[k].x == tag && v[k].z == tag;
+#ifdef C3D_STAMPS
+                if (stamper) cacc[9] += 1;
+#endif
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                // ~0.3 s: the workgroups of this replica are not all resident; or another workgroup has already given up
+                if (spins > (1u << 18) || ((spins & 1023u) == 0 && *timeout != 0u)) {
+                    if (lane == 0) *timeout = 1u;
+                    return;
+                }
+            }
+            CSTAMP(7);                              // gather: sweeps until every tag matches
+#pragma unroll
+            for (int k = 0; k < KUMAX; ++k)
+                if (k < ku) { smem[gda[k]] = __uint_as_float(v[k].y); smem[gdb[k]] = __uint_as_float(v[k].w); }
+        }
+      }
+    }
+}
+
+#ifdef C3D_STAMPS
+hipError_t read_debug_forces(float* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbgF), sizeof(float) * 2 * 6 * 1024); }
+hipError_t read_cluster_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamps), sizeof(unsigned long long) * 16); }
+#endif
+
+// ---- host side ---------------------------------------------------------------------------------------
+// Geometry.  A workgroup = CW compute waves x RPW rows (RW = CW * RPW rows, a multiple of 8, at most 64) + 4 helpers;
+// a replica = P = ceil(n / RW) workgroups; the replicas of the fullest XCD must fit its CUs, one workgroup per CU.
+// Among the geometries that fit, the cheapest by an instruction-count model of one step (VALU issue is the limiter):
+//   per SIMD: ceil(CW / 4) compute waves x (RPW rows x NB blocks x 4 columns x 15 + 60) wave-instructions,
+//   + H0's serial tail (~200) + the hand-off (~570 instruction-times = 0.8 us) unless P == 1.
+bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan) {
+    if (m.npad > 1024 || num_cus < 8 || num_cus % 8) return false;
+    const int cus_per_xcd = num_cus / 8;
+    const int per_xcd = (m.nrep_g + 7) / 8;
+    const int nb = m.npad / 256;
+    static const int geoms[][2] = {{8, 1}, {8, 2}, {12, 2}, {8, 4}, {10, 4}, {12, 4}, {8, 3}, {4, 2}, {4, 4}, {6, 4}};   // {CW, RPW}
+    double best = 1e30;
+    bool found = false;
+    const char* force = getenv("C3D_CLUSTER_GEOM");   // diagnostic: "CWxRPW", e.g. 12x4
+    int fcw = 0, frpw = 0;
+    if (force && sscanf(force, "%dx%d", &fcw, &frpw) != 2) fcw = frpw = 0;
+    for (const auto& g : geoms) {
+        const int cw = g[0], rpw = g[1], rw = cw * rpw;
+        if (fcw && (cw != fcw || rpw != frpw)) continue;
+        if (rw % 8 || rw > 64) continue;
+        if (rpw * nb > 8) continue;               // targets + weights in registers: 2 * rpw * nb float4 per lane
+        const int P = (m.n + rw - 1) / rw;
+        if (per_xcd * P > cus_per_xcd) continue;
+        const int threads = (cw + kClHelpers) * 64;
+        const int kumax = nb > 2 ? 3 : 2;
+        if (P * 2 * rw > threads * kumax) continue;
+        const int wps = (cw + 3) / 4;             // compute waves per SIMD; a lone wave issues at ~0.6 of the multi-wave rate
+        const double cost = (wps == 1 ? 1.6 : (wps == 2 ? 1.15 : 1.0)) * wps * (rpw * nb * 60.0 + 60.0) + 200.0 + (P > 1 ? 570.0 : 0.0);
+        if (cost < best) {
+            best = cost; found = true;
+            plan->rpw = rpw; plan->cw = cw; plan->parts = P; plan->per_xcd = per_xcd; plan->grid = num_cus; plan->threads = threads;
+            plan->units = 2 * rw; plan->device = 0;
+            plan->lds = 84 * 1024;                // more than half of a CU's 160 KB: one workgroup per CU
+        }
+    }
+    return found;
+}
+
+size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl) { return (size_t)2 * m.nrep_g * pl.parts * pl.units * 16; }
+
+template <int POT, int RPW, int NB, bool RS1>
+static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
+                             const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
+                             hipStream_t s) {
+    static bool attr_set[64] = {};                // per device: more dynamic LDS than the 64 KB a launch gets by default
+    const int dev = pl.device & 63;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, RS1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((k_cluster<POT, RPW, NB, RS1>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
+                       run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, m, fp);
+    return hipGetLastError();
+}
+template <int POT>
+static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
+                               const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
+                               hipStream_t s) {
+#define C3D_CL(R, B)                                                                                                    \
+    if (pl.rpw == R && m.npad == 256 * B)                                                                               \
+        return m.rs == 1.0f ? cluster_go<POT, R, B, true>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s) \
+                            : cluster_go<POT, R, B, false>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s)
+    C3D_CL(1, 1); C3D_CL(1, 2); C3D_CL(1, 3); C3D_CL(1, 4);
+    C3D_CL(2, 1); C3D_CL(2, 2); C3D_CL(2, 3); C3D_CL(2, 4);
+    C3D_CL(3, 1); C3D_CL(3, 2);
+    C3D_CL(4, 1); C3D_CL(4, 2);
+#undef C3D_CL
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
+                          const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
+                          hipStream_t s) {
+    switch (m.noe_pot) {
+        case 0: return cluster_geom<0>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
+        case 1: return cluster_geom<1>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
+        default: return cluster_geom<2>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
+    }
+}
+
+AnnealIO anneal_io(const DevBuffers& b, int parity) {
+    const int q = parity ^ 1;
+    AnnealIO io;
+    io.pin = b.P[parity]; io.xin = b.X[parity]; io.vin = b.V[parity]; io.vinit = b.Vinit; io.sin = b.S[parity];
+    io.xout = b.X[q]; io.vout = b.V[q]; io.pout = b.P[q]; io.sout = b.S[q];
+    return io;
+}
+
+}  // namespace c3d

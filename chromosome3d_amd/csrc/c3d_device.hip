@@ -59,7 +59,7 @@ inline dim3 grid_blocks(const DevModel& m) { return dim3(8, m.nrep_g, (m.ntiles 
 //   4. lanes 0..RPW-1 finish one row each; tile partial sums through LDS
 // ---------------------------------------------------------------------------------------------
 
-template <int POT, bool GEN, int RPW>
+template <int POT, bool GEN, int RPW, bool RS1>
 __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     const float* __restrict__ pin, const float* __restrict__ xin, const float* __restrict__ tgt,
     const float* __restrict__ vin, const float* __restrict__ vinit, const FireState* __restrict__ sin,
@@ -87,11 +87,12 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     float* xs = smem;
     float* ys = smem + npad;
     float* zs = smem + 2 * npad;
-    float* wpart = smem + 3 * npad;             // [WAVES][4]
+    float* rowq = smem + 3 * npad;              // [kTileRows][4] per-row contributions to the replica sums
     const size_t roff = (size_t)rep * 3 * npad;
     const int row0 = tile * kTileRows + wave * RPW;
-    const int row = row0 + (lane & (RPW - 1));  // the row this lane finishes (lanes < RPW only)
-    const bool finisher = lane < RPW && row < m.n;
+    const int row = row0 + lane;                // the row this lane finishes (lanes < RPW only)
+    const bool fin_lane = lane < RPW;
+    const bool finisher = fin_lane && row < m.n;
     const size_t ix = roff + row, iy = ix + npad, iz = iy + npad;
     const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
 
     // ---- 3. K2: pair forces for this wave's rows ---------------------------------------------
     float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
-    if (p.kind != 4) tile_forces<POT, GEN, RPW>(m, p, tgt, xs, ys, zs, row0, lane, tv, Fx, Fy, Fz);
+    if (p.kind != 4) tile_forces<POT, GEN, RPW, RS1>(m, p, tgt, xs, ys, zs, row0, lane, tv, Fx, Fy, Fz);
 
     C3D_STAMP(4);
     // ---- 4. epilogue: lanes 0..RPW-1 finish one row each --------------------------------------
@@ -144,34 +145,31 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
         xout[ix] = xn; xout[iy] = yn; xout[iz] = zn;
         vout[ix] = vx; vout[iy] = vy; vout[iz] = vz;
     }
-    q.x = quad_sum<RPW>(q.x); q.y = quad_sum<RPW>(q.y); q.z = quad_sum<RPW>(q.z); q.w = quad_sum<RPW>(q.w);
-    // tile partial sums: fixed-order sum over the waves (deterministic)
-    if (lane == 0) reinterpret_cast<float4*>(wpart)[wave] = q;
+    // tile partial sums: the fixed tree of tile_sum8 over the eight rows (deterministic, the cluster kernel's order)
+    if (fin_lane) reinterpret_cast<float4*>(rowq)[row - tile * kTileRows] = q;
     __syncthreads();
-    if (tid == 0) {
-        float4 t = make_float4(0, 0, 0, 0);
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const float4 u = reinterpret_cast<float4*>(wpart)[w];
-            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-        }
-        reinterpret_cast<float4*>(pout)[(size_t)rep * m.ntiles + tile] = t;
-    }
+    if (tid == 0) reinterpret_cast<float4*>(pout)[(size_t)rep * m.ntiles + tile] = tile_sum8(reinterpret_cast<const float4*>(rowq));
     C3D_STAMP(5);
 }
 
 #ifdef C3D_STAMPS
+hipError_t read_debug_forces_step(float* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbgF), sizeof(float) * 2 * 6 * 1024); }
 hipError_t read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16); }
 #endif
 
-static size_t step_lds_bytes(const DevModel& m) { return sizeof(float) * ((size_t)3 * m.npad + 4 * kTileRows); }
+static size_t step_lds_bytes(const DevModel& m) { return sizeof(float) * ((size_t)3 * m.npad + 4 * kTileRows); }   // xyz + rowq
 
 template <int POT, bool GEN, int RPW>
 static hipError_t launch_step_r(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
                                 hipStream_t s) {
     const int q = par ^ 1;
-    hipLaunchKernelGGL((k_step<POT, GEN, RPW>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
-                       b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
+    // RS1: the CNS-default switch distance of 1 A (rs / d is the reciprocal distance itself); only the default tail has it
+    if (!GEN && m.rs == 1.0f)
+        hipLaunchKernelGGL((k_step<POT, GEN, RPW, !GEN>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
+                           b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
+    else
+        hipLaunchKernelGGL((k_step<POT, GEN, RPW, false>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
+                           b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
     return hipGetLastError();
 }
 template <int POT, bool GEN>

@@ -79,24 +79,32 @@ hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuff
 hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe,
                          float k_rep, hipStream_t s);
 hipError_t launch_centre(const DevModel& m, const DevBuffers& b, int parity, hipStream_t s);
-// resident multi-step kernel (c3d_resident.hip): the steps of runs[0..nruns) (nsteps in all) in ONE launch for every replica; reads parity
-// `parity`, writes parity^1 once at the end.  rec = anneal_record_bytes() of zeroed device memory, *timeout = 0.
-bool anneal_supported(const DevModel& m);
-size_t anneal_record_bytes(const DevModel& m);
-hipError_t anneal_blocks_per_cu(const DevModel& m, bool general_tail, int* blocks_per_cu);
 struct StepRun {    // `count` consecutive steps with the same parameters
     DevStep p;
     int count;
 };
-struct AnnealIO {   // state buffers of one launch, in device memory (io = anneal_io(buffers, parity) uploaded by the host)
+struct AnnealIO {   // state buffers of one multi-step launch, in device memory (io = anneal_io(buffers, parity) uploaded by the host)
     const float *pin, *xin, *vin, *vinit;
     const FireState* sin;
     float *xout, *vout, *pout;
     FireState* sout;
 };
 AnnealIO anneal_io(const DevBuffers& b, int parity);
-hipError_t launch_anneal(const DevModel& m, const DevFire& fp, const AnnealIO* io, const float* tgt, bool general_tail, void* rec,
-                         const StepRun* runs, int nruns, int nsteps, unsigned* timeout, hipStream_t s);
+// cluster kernel (c3d_cluster.hip): many SA steps of the replica group [m.rep_base, m.rep_base + m.nrep_g) in ONE launch;
+// reads parity `parity` (through io), writes parity^1 once at the end.  A replica runs on `parts` workgroups of `threads`
+// threads (`cw` compute waves x `rpw` rows + 4 helper waves) of ONE XCD, one workgroup per CU, grid = number of CUs.
+// `runs` is the run-length coded step list of the WHOLE program (uploaded once); the launch starts `skip0` steps into
+// run `run0` and makes `nsteps` steps.  `tag_base` (launch sequence number << 20) keeps the tags of different launches
+// apart, `claim` points at 8 zeroed slot counters that no other launch has used, *timeout = 0.
+struct ClusterPlan {
+    int rpw, cw, parts, per_xcd, grid, threads, units, device;
+    size_t lds;
+};
+bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan);
+size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl);
+hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
+                          const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout,
+                          unsigned* claim, hipStream_t s);
 // K1: IF (n*n fp64, device) -> dist10 (n*n int32, device) and encoded targets (n*npad, device)
 hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, double K, int min_sep, int rep_sep,
                                double* scratchP, double* partial, int npartial, int32_t* dist10, float* tgt,

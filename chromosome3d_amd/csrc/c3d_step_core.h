@@ -1,6 +1,6 @@
 // c3d_step_core.h — device-side building blocks of one SA step, shared by the per-step kernel
-// (k_step, c3d_device.hip) and the resident multi-step kernel (k_anneal, c3d_resident.hip).  Both kernels
-// run exactly these functions in the same order, so their trajectories are bit-identical.
+// (k_step, c3d_device.hip) and the multi-step cluster kernel (k_cluster, c3d_cluster.hip).  Both kernels
+// form every row's force and every sum in the same order, so their trajectories are bit-identical.
 #pragma once
 #include "c3d_internal.h"
 
@@ -9,6 +9,11 @@
 #pragma clang fp contract(off)
 
 namespace c3d {
+
+#ifdef C3D_STAMPS
+// diagnostic build: pair sum and chain sum of every row of replica 0 at the last evaluation, per kernel (0 k_step, 1 k_cluster)
+static __device__ float g_dbgF[2][6][1024];   // one copy per translation unit
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -47,9 +52,12 @@ __device__ __forceinline__ float quad_sum(float v) {
 // (lane parity picks which row a lane keeps), every later level preserves lane & 3.
 template <int RPW>
 __device__ __forceinline__ float reduce_rows(const float (&a)[RPW], int lane) {
-    static_assert(RPW == 1 || RPW == 2 || RPW == 4, "rows per wave must be 1, 2 or 4");
+    static_assert(RPW >= 1 && RPW <= 4, "rows per wave must be 1..4");
     float k;
-    if constexpr (RPW == 1) {
+    if constexpr (RPW == 3) {   // the four-row tree with an empty fourth row: rows 0..2 get the bits they get there
+        const float a4[4] = {a[0], a[1], a[2], 0.0f};
+        return reduce_rows<4>(a4, lane);
+    } else if constexpr (RPW == 1) {
         k = a[0];
         k += dpp_mov<0xB1>(k);
         k += dpp_mov<0x4E>(k);
@@ -108,28 +116,32 @@ __device__ __forceinline__ void tile_prefetch(const DevModel& m, const float* __
         tv[r] = *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 256 * jb + 4 * lane);
 }
 
-// One pair term.  F_i += c * (x_i - x_j) with c = -(dE/dd)/d.  Written to minimise VALU issue slots
-// (this is the inner loop of the whole solver):
+// One pair term.  F_i += c * (x_i - x_j) with c = -(dE/dd)/d.  Written to minimise VALU issue slots: the solver is
+// bound by VALU issue (one wave64 instruction holds its SIMD ~4 cycles; tools/microbench/valu_rate), so every
+// instruction of this function costs ~1.4 ns x pairs / lanes on the whole chip:
 //   r2 carries a +1e-12 guard inside the fma chain (no separate max);
 //   NOE, CNS-default tail (slope 2 rs): with u = (d - t)/d = 1 - t/d the clamp of the soft-square acts on
-//   u directly: -(dE/dd)/d = -2 w S min(u, rs/d)  (d itself is never formed);
+//   u directly: -(dE/dd)/d = -2 w S min(u, rs/d)  (d itself is never formed); RS1: rs == 1, rs/d is rinv itself;
+//   mw = -2 w S where the pair is restrained, 0 where it is not: mask and weight are ONE multiply (the resident
+//   kernels keep mw in registers per run of equal steps, the per-step kernel forms it from the target);
 //   repel: max(0, R2 - r2) = R2 * clamp01(1 - r2/R2) is ONE v_fma_f32 with the clamp output modifier.
-template <int POT, bool GEN>
-__device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, float v, float dx, float dy, float dz,
+template <int POT, bool GEN, bool RS1>
+__device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, float v, float mw, float dx, float dy, float dz,
                                           float& fx, float& fy, float& fz) {
     const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, 1e-12f)));
     const float rinv = __builtin_amdgcn_rsqf(r2);
     float s;   // (dE/dd) / (2 d) without the weights
     if constexpr (!GEN) {
         const float u = fmaf(-v, rinv, 1.0f);          // (d - t) / d
-        const float lim = m.rs * rinv;                 // rs / d
+        float lim;                                     // rs / d
+        if constexpr (RS1) lim = rinv; else lim = m.rs * rinv;
         if constexpr (POT == 1) s = fminf(u, lim);
         else if constexpr (POT == 0) s = fminf(fmaxf(u, -lim), lim);
         else s = u;
     } else {
         s = 0.5f * noe_grad<POT, GEN>(r2 * rinv - v, m) * rinv;
     }
-    float c = (v > 0.0f) ? p.w_noe2n * s : 0.0f;      // v = target (A), 0 = no restraint; w_noe2n = -2 w S
+    float c = mw * s;
     // repel on EVERY column: padding beads are 1e4 A away (q = 0), the self term has dx = 0, and the
     // |i-j| < rep_sep neighbours are taken back out in the chain-term pass below
     float q01;   // clamp01(1 - r2/R2): the clamp is an output modifier of the fma (hipcc has no builtin for it)
@@ -140,31 +152,32 @@ __device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, f
     fz = fmaf(c, dz, fz);
 }
 
-// the four pair terms of one lane and one row against columns j .. j+3 (targets tv)
-template <int POT, bool GEN>
-__device__ __forceinline__ void pair_quad(const DevModel& m, const DevStep& p, const float4 tv, float xi, float yi, float zi,
-                                          const float4 xj, const float4 yj, const float4 zj, float& fx, float& fy, float& fz) {
-    pair_term<POT, GEN>(m, p, tv.x, xi - xj.x, yi - yj.x, zi - zj.x, fx, fy, fz);
-    pair_term<POT, GEN>(m, p, tv.y, xi - xj.y, yi - yj.y, zi - zj.y, fx, fy, fz);
-    pair_term<POT, GEN>(m, p, tv.z, xi - xj.z, yi - yj.z, zi - zj.z, fx, fy, fz);
-    pair_term<POT, GEN>(m, p, tv.w, xi - xj.w, yi - yj.w, zi - zj.w, fx, fy, fz);
+// per-pair NOE weights of four targets: -2 w S where a restraint exists (target > 0), else 0
+__device__ __forceinline__ float4 noe_weights(const DevStep& p, const float4 tv) {
+    return make_float4(tv.x > 0.0f ? p.w_noe2n : 0.0f, tv.y > 0.0f ? p.w_noe2n : 0.0f, tv.z > 0.0f ? p.w_noe2n : 0.0f,
+                       tv.w > 0.0f ? p.w_noe2n : 0.0f);
 }
 
-// chain terms: pseudo-bond (i,i+-1), pseudo-angle (i,i+-2) and the repel take-back for |i-j| < rep_sep.
-// Lane l < 4*RPW handles neighbour (l & 3) of row (l >> 2) — one pass for all rows; then the transposing
-// reduction that leaves the force on row row0 + (l & (RPW-1)) in lane l.
-template <int RPW>
-__device__ __forceinline__ void chain_and_reduce(const DevModel& m, const DevStep& p, const float* xs, const float* ys,
-                                                 const float* zs, int row0, int lane, float (&fx)[RPW], float (&fy)[RPW],
-                                                 float (&fz)[RPW], float& Fx, float& Fy, float& Fz) {
-    const int nb = lane & 3;
+// the four pair terms of one lane and one row against columns j .. j+3 (targets tv, weights mw)
+template <int POT, bool GEN, bool RS1>
+__device__ __forceinline__ void pair_quad(const DevModel& m, const DevStep& p, const float4 tv, const float4 mw, float xi, float yi,
+                                          float zi, const float4 xj, const float4 yj, const float4 zj, float& fx, float& fy, float& fz) {
+    pair_term<POT, GEN, RS1>(m, p, tv.x, mw.x, xi - xj.x, yi - yj.x, zi - zj.x, fx, fy, fz);
+    pair_term<POT, GEN, RS1>(m, p, tv.y, mw.y, xi - xj.y, yi - yj.y, zi - zj.y, fx, fy, fz);
+    pair_term<POT, GEN, RS1>(m, p, tv.z, mw.z, xi - xj.z, yi - yj.z, zi - zj.z, fx, fy, fz);
+    pair_term<POT, GEN, RS1>(m, p, tv.w, mw.w, xi - xj.w, yi - yj.w, zi - zj.w, fx, fy, fz);
+}
+
+// One chain term: neighbour nb (0..3 = offsets -2,-1,+1,+2) of `row`: pseudo-bond (i,i+-1), pseudo-angle (i,i+-2) and the
+// repel take-back for |i-j| < rep_sep (the pair loop applies the repel term to every column).  `active` = the lane
+// has a row; returns the force contribution on `row` (0 where the neighbour does not exist).
+__device__ __forceinline__ void chain_term(const DevModel& m, const DevStep& p, const float* xs, const float* ys, const float* zs,
+                                           int row, int nb, bool active, float& cx, float& cy, float& cz) {
     const int off = nb < 2 ? nb - 2 : nb - 1;          // -2,-1,+1,+2
     const int sep = off < 0 ? -off : off;
-    const int rsel = lane >> 2;                          // row of this lane (valid while lane < 4*RPW)
-    const int row = min(row0 + rsel, m.n - 1);
     const int jn = row + off;
-    float cx = 0.0f, cy = 0.0f, cz = 0.0f;
-    if (lane < 4 * RPW && row0 + rsel < m.n && jn >= 0 && jn < m.n) {
+    cx = cy = cz = 0.0f;
+    if (active && row < m.n && jn >= 0 && jn < m.n) {
         const float dx = xs[row] - xs[jn], dy = ys[row] - ys[jn], dz = zs[row] - zs[jn];
         const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
         const float rinv = __builtin_amdgcn_rsqf(r2);
@@ -176,20 +189,52 @@ __device__ __forceinline__ void chain_and_reduce(const DevModel& m, const DevSte
         if (sep < m.rep_sep) c = fmaf(-p.w_rep4, fmaxf(p.rep_r2 - r2, 0.0f), c);
         cx = c * dx; cy = c * dy; cz = c * dz;
     }
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const bool mine = rsel == r;
-        fx[r] += mine ? cx : 0.0f;
-        fy[r] += mine ? cy : 0.0f;
-        fz[r] += mine ? cz : 0.0f;
-    }
+}
+// sum of the four chain terms of a row held by the four lanes of a quad, (c0 + c1) + (c2 + c3), in every lane of it
+__device__ __forceinline__ float quad_chain_sum(float c) {
+    c += dpp_mov<0xB1>(c);
+    c += dpp_mov<0x4E>(c);
+    return c;
+}
+
+// The force on a row = [butterfly sum over the 64 lanes of the pair terms, as it comes out in lane r < 4 (the tree's
+// association differs from quad to quad)] + [(c-2 + c-1) + (c+1 + c+2)]: every kernel forms it in exactly this order, so a
+// row's force has the same bits whatever the geometry (rows per wave, which wave or workgroup owns the row).
+// Here (per-step kernel, forces hook): rows row0 .. row0+RPW-1 of one wave.  Chain terms: neighbour nb of row i is
+// evaluated by lane 4 (i & 1) + nb, two rows per pass; the quad sums are then brought to lane r = i - row0, the row's
+// finisher (lanes 0 .. RPW-1).
+template <int RPW>
+__device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevStep& p, const float* xs, const float* ys,
+                                                 const float* zs, int row0, int lane, float (&fx)[RPW], float (&fy)[RPW],
+                                                 float (&fz)[RPW], float& Fx, float& Fy, float& Fz) {
     Fx = reduce_rows<RPW>(fx, lane);
     Fy = reduce_rows<RPW>(fy, lane);
     Fz = reduce_rows<RPW>(fz, lane);
+    const int nb = lane & 3, half = (lane >> 2) & 1;     // lanes 0..3 serve even rows, 4..7 odd rows
+#pragma unroll
+    for (int pass = 0; pass < (RPW + 1) / 2; ++pass) {
+        // the row of {row0 + 2 pass, row0 + 2 pass + 1} whose parity is `half`
+        const int rsel = 2 * pass + ((half ^ row0) & 1);
+        float cx, cy, cz;
+        chain_term(m, p, xs, ys, zs, row0 + rsel, nb, lane < 8 && rsel < RPW, cx, cy, cz);
+        cx = quad_chain_sum(cx); cy = quad_chain_sum(cy); cz = quad_chain_sum(cz);
+        // lane r < 4 takes its own quad's sum if that is its row's, else the sum of lanes 4..7 (row_ror:12 = lane + 4)
+        const float ox = dpp_mov<0x12C>(cx), oy = dpp_mov<0x12C>(cy), oz = dpp_mov<0x12C>(cz);
+        const bool own = lane == rsel, other = lane == (rsel ^ 1);   // in lanes 0..3 rsel is the even-quad row of this pass
+#ifdef C3D_STAMPS
+        if (m.rep_base == 0 && blockIdx.y == 0 && lane < RPW && (own || other) && row0 + lane < 1024) {
+            g_dbgF[0][0][row0 + lane] = Fx; g_dbgF[0][1][row0 + lane] = Fy; g_dbgF[0][2][row0 + lane] = Fz;
+            g_dbgF[0][3][row0 + lane] = own ? cx : ox; g_dbgF[0][4][row0 + lane] = own ? cy : oy; g_dbgF[0][5][row0 + lane] = own ? cz : oz;
+        }
+#endif
+        Fx += own ? cx : (other ? ox : 0.0f);
+        Fy += own ? cy : (other ? oy : 0.0f);
+        Fz += own ? cz : (other ? oz : 0.0f);
+    }
 }
 
 // targets streamed from global memory, one column block ahead (per-step kernel)
-template <int POT, bool GEN, int RPW>
+template <int POT, bool GEN, int RPW, bool RS1 = false>
 __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p, const float* __restrict__ tgt,
                                             const float* xs, const float* ys, const float* zs, int row0, int lane,
                                             float4 (&tv)[RPW], float& Fx, float& Fy, float& Fz) {
@@ -211,18 +256,22 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
         const float4 yj = *reinterpret_cast<const float4*>(ys + j);
         const float4 zj = *reinterpret_cast<const float4*>(zs + j);
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) pair_quad<POT, GEN>(m, p, tv[r], xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+        for (int r = 0; r < RPW; ++r)
+            pair_quad<POT, GEN, RS1>(m, p, tv[r], noe_weights(p, tv[r]), xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) tv[r] = tn[r];
     }
-    chain_and_reduce<RPW>(m, p, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
+    reduce_and_chain<RPW>(m, p, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
 }
 
-// targets resident in registers for the whole launch (resident kernel): NB column blocks, fully unrolled
-template <int POT, bool GEN, int RPW, int NB>
-__device__ __forceinline__ void tile_forces_reg(const DevModel& m, const DevStep& p, const float4 (&tv)[RPW][NB],
-                                                const float* xs, const float* ys, const float* zs, int row0, int lane,
-                                                float& Fx, float& Fy, float& Fz) {
+// targets and NOE weights resident in registers for a whole run of equal steps (cluster kernel, compute waves): NB
+// column blocks, fully unrolled.  Returns the butterfly sums of the PAIR terms only: lane l holds the sum for row
+// row0 + (l & 3) (RPW >= 3), row0 + (l & 1) (RPW = 2), row0 (RPW = 1); the chain terms are added by the finishing wave.
+// NARROW = keep only four pair terms in flight (register budget).
+template <int POT, int RPW, int NB, bool NARROW, bool RS1>
+__device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevStep& p, const float4 (&tv)[RPW][NB],
+                                                   const float4 (&mw)[RPW][NB], const float* xs, const float* ys, const float* zs,
+                                                   int row0, int lane, float& Fx, float& Fy, float& Fz) {
     float fx[RPW], fy[RPW], fz[RPW];
     float xi[RPW], yi[RPW], zi[RPW];
 #pragma unroll
@@ -239,14 +288,13 @@ __device__ __forceinline__ void tile_forces_reg(const DevModel& m, const DevStep
         const float4 zj = *reinterpret_cast<const float4*>(zs + j);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            pair_quad<POT, GEN>(m, p, tv[r][jb], xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
-            // four pair terms in flight, not 4 * RPW * NB: this row's sums must exist before the next row's
-            // coordinates may be used (the resident launch needs 5 waves per SIMD, i.e. <= 96 VGPRs)
-            const int rn = (r + 1) % RPW;
-            asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]), "+v"(xi[rn]), "+v"(yi[rn]), "+v"(zi[rn]));
+            pair_quad<POT, false, RS1>(m, p, tv[r][jb], mw[r][jb], xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+            if constexpr (NARROW) asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]));   // four pair terms in flight, not 4 RPW NB
         }
     }
-    chain_and_reduce<RPW>(m, p, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
+    Fx = reduce_rows<RPW>(fx, lane);
+    Fy = reduce_rows<RPW>(fy, lane);
+    Fz = reduce_rows<RPW>(fz, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -324,6 +372,17 @@ __device__ __forceinline__ void finish_row(const DevModel& m, const DevStep& p, 
         const float scl = d2 > fp.max_step * fp.max_step ? fp.max_step * __builtin_amdgcn_rsqf(d2) : 1.0f;
         xn = fmaf(scl, dxs, x0); yn = fmaf(scl, dys, y0); zn = fmaf(scl, dzs, z0);
     }
+}
+
+// one tile's (8 rows) sums from the rows' contributions q[0..7], a fixed tree: ((q0+q1) + (q2+q3)) + ((q4+q5) + (q6+q7))
+__device__ __forceinline__ float4 tile_sum8(const float4* q) {
+    float4 h[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float4 a = q[4 * k], b = q[4 * k + 1], c = q[4 * k + 2], d = q[4 * k + 3];
+        h[k] = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+    }
+    return make_float4(h[0].x + h[1].x, h[0].y + h[1].y, h[0].z + h[1].z, h[0].w + h[1].w);
 }
 
 __device__ __forceinline__ float4 wave_sum4(float4 a) {

@@ -140,6 +140,15 @@ class Solver:
         _l.check(self._L.c3d_last_timing(self._h, C.byref(ms), C.byref(st), C.byref(la)))
         return ms.value, st.value, la.value
 
+    def stat(self, key):
+        v = C.c_double()
+        _l.check(self._L.c3d_get_stat(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    @property
+    def step_kernel_name(self):
+        return self._L.c3d_step_kernel_name(self._h).decode()
+
     def eval(self, w_all=1.0, w_vdw=1.0, repel_s=0.85, forces=True, energies=True):
         F = np.empty((self.nrep, self.n, 3), dtype=np.float32) if forces else None
         e = np.empty((self.nrep, 3), dtype=np.float64) if energies else None

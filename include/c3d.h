@@ -135,6 +135,14 @@ long c3d_steps_done(const c3d_ctx* ctx);
 int c3d_centre(c3d_ctx* ctx);
 /* device time of the last c3d_run / c3d_run_steps, from HIP events on the solver's stream */
 int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* launches);
+/* Counters of the context since c3d_create, for benchmarks and tests (no reference counterpart: the reference's
+ * only instrument is the wall clock around `./job.sh`, chromosome3D.pl:287).  Keys: "graph_captures" (hipGraphs
+ * captured + instantiated), "graph_launches", "graphs_cached", "step_launches" (k_step dispatches), "resident_launches",
+ * "cluster_launches", "resident_fallbacks" (multi-step launches abandoned for the per-step path), "last_path"
+ * (0 per-step, 1 k_anneal, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "replica_groups". */
+int c3d_get_stat(const c3d_ctx* ctx, const char* key, double* value);
+/* Name of the step kernel the last c3d_run / c3d_run_steps ran on, as a profiler prints it (thread-local string). */
+const char* c3d_step_kernel_name(const c3d_ctx* ctx);
 
 /* One evaluation through the production pair kernel at the replicas' current coordinates:
  * F (n_replicas*n*3) = total weighted force; e (n_replicas*3) = unweighted (noe, bond+angle,

@@ -1,4 +1,4 @@
-"""Debug aid: first step at which the resident kernel and the per-step kernel disagree."""
+"""Debug aid: first step at which the multi-step cluster kernel and the per-step kernel disagree."""
 import sys
 
 import numpy as np
@@ -10,12 +10,14 @@ from tests.util import load_if  # noqa: E402
 
 def state(cid, nrep, k, resident):
     s = Solver(0)
-    s.set_model(default_model())
+    s.set_model(default_model(**{kv.split("=")[0][2:]: float(kv.split("=")[1]) for kv in sys.argv[3:] if kv.startswith("m:")}))
     s.set_if_matrix(load_if(cid))
     s.set_schedule(default_schedule(300), None, 0.0, 250)
     s.set_option("resident", resident)
     s.set_option("resident_min_ops", 1)
     for kv in sys.argv[3:]:
+        if kv.startswith("m:"):
+            continue
         key, val = kv.split("=")
         s.set_option(key, float(val))
     s.init_replicas(nrep, 82364, 0)
@@ -34,7 +36,10 @@ def main():
         print(f"{cid} k={k:5d} max|dx|={dx:.3e} max|dv|={dv:.3e} nan={np.isnan(xb).any()}", flush=True)
         if dx > 0 or dv > 0:
             bad = np.argwhere(np.abs(xa - xb) > 0)
-            print("  first differing (replica, bead, comp):", bad[:5].tolist(), "of", len(bad))
+            print("  first differing x (replica, bead, comp):", bad[:5].tolist(), "of", len(bad))
+            badv = np.argwhere(np.abs(va - vb) > 0)
+            print("  first differing v (replica, bead, comp):", badv[:8].tolist(), "of", len(badv), "of", va.size)
+            print("  beads:", sorted(set(int(b[1]) for b in badv))[:40])
             break
 
 
