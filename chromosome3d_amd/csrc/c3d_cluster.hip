@@ -72,6 +72,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     float* cbuf = fbuf + 3 * 64;                  // [3][64] chain sums of this workgroup's rows (H1..H3 -> H0)
     float* dump = cbuf + 3 * 64;                  // [4] nobody reads
     int* s_slot = reinterpret_cast<int*>(dump + 4);
+    float4* mwbuf = reinterpret_cast<float4*>(dump + 8);   // [CW][RPW * NB][64] NOE weights of the current run
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = (CW + kClHelpers) * 64;
     const int RW = CW * RPW;                      // rows of one workgroup: a multiple of 8 (whole tiles), <= 64
@@ -86,6 +87,8 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const int rep = m.rep_base + lrep;
     const bool solo = P == 1;
     const bool is_compute = wave < CW, is_h0 = wave == CW;
+    // the helpers' instruction chains are the serial part of a step: they issue ahead of the compute waves of their SIMD
+    if (!is_compute) __builtin_amdgcn_s_setprio(3);
 
     const size_t roff = (size_t)rep * 3 * NPAD;
     const int wg_row0 = part * RW;
@@ -148,11 +151,14 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
       const DevStep p = runs[run].p;
       const int count = runs[run].count;
       const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
-      float4 mw[RPW][NB];                           // NOE weight of every pair of this wave for this run: -2 w S or 0
+      // NOE weight of every pair of this wave for this run (-2 w S or 0): wave-private LDS, no barrier needed
+      float4* const mw = mwbuf + (size_t)wave * (RPW * NB * 64);
+      if (is_compute) {
 #pragma unroll
-      for (int r = 0; r < RPW; ++r)
+          for (int r = 0; r < RPW; ++r)
 #pragma unroll
-          for (int jb = 0; jb < NB; ++jb) mw[r][jb] = noe_weights(p, tv[r][jb]);
+              for (int jb = 0; jb < NB; ++jb) mw[(r * NB + jb) * 64 + lane] = noe_weights(p, tv[r][jb]);
+      }
       for (int it = run == run0 ? skip0 : 0; it < count; ++it, ++s) {
         CSTAMP(0);                                  // LDS writes of the gather / loop bookkeeping
         __syncthreads();                            // B1: xs/ys/zs/ps of this step are in LDS
@@ -263,6 +269,9 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         if (last) return;
         if (solo) continue;
         CSTAMP(6);                                  // publish
+        // B3: nobody polls before this workgroup's own record is out — fifteen spinning waves would take the issue
+        // slots H0's update needs, and no gather can finish earlier than that anyway
+        __syncthreads();
         // ---- gather the replica's records of step s+1 into LDS: re-read until every tag matches ----------
         {
             u32x4 v[KUMAX];
@@ -338,7 +347,10 @@ bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan) {
             best = cost; found = true;
             plan->rpw = rpw; plan->cw = cw; plan->parts = P; plan->per_xcd = per_xcd; plan->grid = num_cus; plan->threads = threads;
             plan->units = 2 * rw; plan->device = 0;
-            plan->lds = 84 * 1024;                // more than half of a CU's 160 KB: one workgroup per CU
+            // coordinates, sums, row buffers + the compute waves' NOE weights; at least 84 KB (more than half of a CU's
+            // 160 KB): one workgroup per CU
+            plan->lds = sizeof(float) * (3 * m.npad + 4 * (m.npad / 8) + 6 * 64 + 16) + (size_t)cw * rpw * nb * 64 * 16;
+            if (plan->lds < 84 * 1024) plan->lds = 84 * 1024;
         }
     }
     return found;
@@ -353,7 +365,7 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
     static bool attr_set[64] = {};                // per device: more dynamic LDS than the 64 KB a launch gets by default
     const int dev = pl.device & 63;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, RS1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, RS1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }

@@ -270,8 +270,10 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
 // NARROW = keep only four pair terms in flight (register budget).
 template <int POT, int RPW, int NB, bool NARROW, bool RS1>
 __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevStep& p, const float4 (&tv)[RPW][NB],
-                                                   const float4 (&mw)[RPW][NB], const float* xs, const float* ys, const float* zs,
+                                                   const float4* mw_lds, const float* xs, const float* ys, const float* zs,
                                                    int row0, int lane, float& Fx, float& Fy, float& Fz) {
+    // mw_lds: this wave's NOE weights of the current run, [RPW * NB][64] float4 in LDS (lane-contiguous: ds_read_b128 at
+    // full rate, no VALU slot); keeping them in registers next to the targets overflows the 128 a wave has at RPW x NB = 8
     float fx[RPW], fy[RPW], fz[RPW];
     float xi[RPW], yi[RPW], zi[RPW];
 #pragma unroll
@@ -288,7 +290,8 @@ __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevS
         const float4 zj = *reinterpret_cast<const float4*>(zs + j);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            pair_quad<POT, false, RS1>(m, p, tv[r][jb], mw[r][jb], xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+            const float4 mw = mw_lds[(r * NB + jb) * 64 + lane];
+            pair_quad<POT, false, RS1>(m, p, tv[r][jb], mw, xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
             if constexpr (NARROW) asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]));   // four pair terms in flight, not 4 RPW NB
         }
     }

@@ -66,10 +66,11 @@ def test_anneal_recovers_synthetic_structure(solver, big):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,nrep", [(256, 3), (257, 3), (600, 2), (1000, 2), (9, 5)])
-def test_resident_kernel_every_column_block_count(solver, n, nrep):
-    """Resident kernel instantiations for 1..4 column blocks (targets held in 8..32 VGPRs), the block
-    boundary N = 256 / 257 and a single-tile problem: same bits as the per-step path after MD and FIRE steps."""
+@pytest.mark.parametrize("n,nrep", [(256, 3), (257, 3), (600, 2), (760, 2), (9, 5), (64, 11), (65, 11)])
+def test_cluster_kernel_every_column_block_count(solver, n, nrep):
+    """Cluster kernel instantiations for 1..3 column blocks (targets held in registers), the block boundary
+    N = 256 / 257, the largest N whose replica fits one XCD's 32 CUs, one-workgroup replicas (N <= 64, no hand-off)
+    and the first size with two workgroups: same bits as the per-step path after MD and FIRE steps."""
     from chromosome3d_amd import default_model, make_stages
     from tests.util import synthetic_if
     IF, _ = synthetic_if(n, seed=7)
@@ -84,6 +85,7 @@ def test_resident_kernel_every_column_block_count(solver, n, nrep):
         solver.run_steps(10 ** 6)
         out.append((solver.coords(), solver.velocities(), solver.last_timing()[2]))
     solver.set_option("resident", -1)
+    assert solver.stat("cluster_parts") >= 1
     assert out[1][2] == 1 and out[0][2] > 60
     assert np.isfinite(out[0][0]).all()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

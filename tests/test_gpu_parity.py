@@ -416,11 +416,12 @@ def _anneal(solver, cid, nrep, resident, inject=False):
     return out
 
 
-@pytest.mark.parametrize("cid,nrep", [("chr21_1mb", 4), ("chr19_500kb", 3), ("chr1_500kb", 3)])
-def test_resident_kernel_is_bit_identical_to_per_step_path(solver, cid, nrep):
-    """The multi-step resident kernel (tile records handed between workgroups inside one launch) and the
-    one-launch-per-step path run the same arithmetic: the whole anneal, early exit included, ends in the
-    same bits."""
+@pytest.mark.parametrize("cid,nrep", [("chr21_1mb", 4), ("chr19_500kb", 3), ("chr1_500kb", 3), ("chr1_500kb", 20), ("chr4_1mb", 20),
+                                      ("chr21_500kb", 17), ("chr13_1mb", 9)])
+def test_cluster_kernel_is_bit_identical_to_per_step_path(solver, cid, nrep):
+    """The multi-step cluster kernel (records handed between the workgroups of a replica inside one launch,
+    through their XCD's L2) and the one-launch-per-step path run the same arithmetic: the whole anneal, early
+    exit included, ends in the same bits."""
     xa, va, ea, ta = _anneal(solver, cid, nrep, 0)
     xb, vb, eb, tb = _anneal(solver, cid, nrep, 1)
     assert ta[1] == tb[1]                       # same number of SA steps (same early exit)
@@ -428,8 +429,8 @@ def test_resident_kernel_is_bit_identical_to_per_step_path(solver, cid, nrep):
     assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(ea, eb)
 
 
-def test_resident_launch_that_times_out_falls_back_to_per_step(solver):
-    """A resident launch whose tiles cannot all be resident gives up (bounded spins) and leaves its inputs
+def test_cluster_launch_that_times_out_falls_back_to_per_step(solver):
+    """A multi-step launch whose workgroups cannot all be resident gives up (bounded spins) and leaves its inputs
     intact; the host then runs the same steps on the per-step path.  The timeout is injected."""
     xa, va, ea, ta = _anneal(solver, "chr21_1mb", 4, 0)
     xb, vb, eb, tb = _anneal(solver, "chr21_1mb", 4, 1, inject=True)
