@@ -2,26 +2,34 @@
 """Headline benchmark: SA steps/s for 20 replicas of chr1_500kb (N = 455 beads, R = 101426
 restraints) per MI355X — BASELINE.json configs[2], the configuration the metric is quoted on.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--scaling weak|strong]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one SA step (force evaluation + coordinate update) of every replica on the GPU =
-one launch of the step kernel.  Every rank runs its own 20 replicas (weak scaling, replica ids
-rank*20 .. rank*20+19, no data-path collective); after the timed region one RCCL all_gather of
-the per-replica records lets rank 0 rank all models (not timed; reported as gather_ms).
+A "step" is one SA step (force evaluation + coordinate update) of every replica on the GPU.
+The timed region is exactly K steps of the real annealing schedule, starting W steps in, bracketed
+by a barrier + device synchronisation on both sides.  The bracket is repeated `reps` times
+(consecutive K-step regions of the same schedule, the next batch of replicas starting when the
+schedule ends); `value` comes from the MEDIAN region wall time, maximum over the ranks.
 
-The timed K steps walk the real annealing schedule (pre-minimisation, 1000 hot MD steps,
-972 cooling MD steps, FIRE minimisation), starting W steps in; when the schedule ends the
-next batch of replicas starts.  Graph capture/instantiation happens in an untimed priming
-pass (it is set-up, like compilation).  Inputs are resident in HBM before the timed region.
+Nothing is built inside a timed region: one untimed pass replays the identical call pattern first
+(hipGraphs of the per-step path are captured there; the multi-step cluster kernel needs none), and
+the library's `graph_captures` counter is asserted unchanged over the timed regions.
 
-Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM,
-algorithmic bytes B = 4R + 72N per replica-step) and `cpu_baseline` (the fp64
-oracle on one host core over a bounded sample of the same workload).
+--scaling weak   (default) every rank runs its own 20 replicas (ids rank*20 ..), no data-path collective
+--scaling strong 20 replicas in all, split 3,3,3,3,2,2,2,2 over the ranks (sharding.replica_range):
+                 the north star's "20 replicas of chr1_500kb at 1/2/4/8 MI355X"
+After the timed regions one all_gather (RCCL) of the per-replica records of a COMPLETE untimed anneal
+lets rank 0 rank all models (reported: gather_ms, spearman_*).
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic
+bytes B = 4R + 72N per replica-step; duration from HIP events on the solver's stream) and
+`cpu_baseline` (the fp64 oracle on the host cores over a bounded sample of the same workload).
 """
 import argparse
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,15 +38,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-REPLICAS_PER_GPU = 20
+REPLICAS = 20
 WORKLOAD = "chr1_500kb"
 MIN_STEPS = 3000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
-def cpu_baseline(IF, d10, model, fire, stages, budget_s=15.0):
-    """Oracle (fp64 C, one core) on a bounded sample: one replica, as many SA steps of the same
-    schedule as fit in ~budget_s.  Returns (replica_steps_per_s, sample description)."""
+def cpu_baseline(IF, d10, model, fire, stages, budget_s=8.0):
+    """Oracle (fp64 C) on a bounded sample: one replica on one core, as many SA steps of the same
+    schedule as fit in ~budget_s; then the same sample on every host core at once."""
     from oracle import oracle as O
     from tests.util import oracle_fire_from, oracle_model_from
     n = IF.shape[0]
@@ -56,20 +64,13 @@ def cpu_baseline(IF, d10, model, fire, stages, budget_s=15.0):
         take = min(r[1], budget_steps - total)
         sample.append((r[0], take) + tuple(r[2:]))
         total += take
-    # whole replicas of the sampled schedule until the sample is >= ~10 s of CPU work
     t0 = time.perf_counter()
-    ev, reps = 0, 0
-    while True:
-        _, _, e1 = O.run_schedule(om, d10, O.make_stages(sample), of, 82364, reps, x0=x)
-        ev += e1
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= 10.0 or reps >= 8:
-            break
-    one_core = ev / dt, (f"{reps} replica(s) of {WORKLOAD}, {ev} SA steps of the same schedule (hot/cool MD + FIRE), "
-                         f"fp64 oracle/c3d_oracle.c, 1 core, {dt:.1f} s")
-    # the same sample on every host core at once, one replica per thread (the reference's way to use a CPU
-    # box is one process per chromosome, test.sh:4-12); ctypes releases the GIL inside the C call
+    _, _, ev = O.run_schedule(om, d10, O.make_stages(sample), of, 82364, 0, x0=x)
+    dt = time.perf_counter() - t0
+    one = (ev / dt, f"1 replica of {WORKLOAD}, {ev} SA steps of the same schedule (hot/cool MD), fp64 oracle/c3d_oracle.c, "
+                    f"1 core, {dt:.1f} s")
+    # the same sample on every host core at once, one replica per thread (the reference's way to use a CPU box is one
+    # process per chromosome, test.sh:4-12); ctypes releases the GIL inside the C call
     import threading
     T = max(1, min(16, os.cpu_count() or 1))
     evs = [0] * T
@@ -86,21 +87,38 @@ def cpu_baseline(IF, d10, model, fire, stages, budget_s=15.0):
     dt = time.perf_counter() - t0
     all_cores = {"value": round(sum(evs) / dt, 1), "unit": "replica-steps/s", "cores": T,
                  "sample": f"{T} replicas at once, one thread each, {sum(evs)} SA steps, {dt:.1f} s"}
-    return one_core[0], one_core[1], all_cores
+    return one[0], one[1], all_cores
+
+
+def hbm_traffic_from_profiles(kernel, n, replicas):
+    """HBM bytes per SA step of `kernel` from the newest profiles/*hbm_traffic*.json that matches (written by
+    tools/pmc_summarise.py from separate rocprofv3 --pmc passes); None when there is none."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json"))):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("kernel", "").split("<")[0] == kernel.split("<")[0] and rec.get("n") == n and rec.get("replicas") == replicas:
+            best = (rec.get("hbm_bytes_per_sa_step"), os.path.relpath(path, ROOT))
+    return best if best else (None, None)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=172)
+    ap.add_argument("--reps", type=int, default=0, help="timed K-step regions (0 = 50 for K <= 100, else 5)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU)
-    ap.add_argument("--groups", type=int, default=0, help="replica groups on separate streams (0 = library default)")
-    ap.add_argument("--resident", type=int, default=-1, help="1/0: resident multi-step kernel on/off (-1 = library default)")
+    ap.add_argument("--replicas", type=int, default=REPLICAS, help="weak: per GPU; strong: in all")
+    ap.add_argument("--groups", type=int, default=0, help="replica groups on separate streams, per-step path (0 = library default)")
+    ap.add_argument("--resident", type=int, default=-1, help="1/0: multi-step cluster kernel on/off (-1 = library default)")
     ap.add_argument("--rpw", type=int, default=0, help="rows per wave of the step kernel (tuning knob; 0 = library default)")
     args = ap.parse_args()
+    reps = args.reps or (50 if args.steps <= 100 else 5)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -121,13 +139,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    on_gpu_group = dist is not None and dist.get_backend() == "nccl"
 
     from chromosome3d_amd import Solver, default_fire, default_model, default_schedule, pipeline, sharding
     from tests.util import load_if
 
     IF = load_if(WORKLOAD)
     n = IF.shape[0]
-    M = args.replicas
+    if args.scaling == "strong":
+        first, M = sharding.replica_range(args.replicas, world, rank)      # 20 over 8 -> 3,3,3,3,2,2,2,2
+        total_replicas = args.replicas
+    else:
+        M, first, total_replicas = args.replicas, rank * args.replicas, args.replicas * world
     s = Solver(local_rank)
     model, fire, stages = default_model(), default_fire(), default_schedule(MIN_STEPS)
     s.set_model(model)
@@ -149,73 +172,91 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- priming pass (untimed): builds every hipGraph of the schedule ----
-    s.init_replicas(M, 82364, 10 ** 6 + rank * M)
-    s.run_steps(L)
-
-    # ---- warmup ----
-    batch = 0
-    s.init_replicas(M, 82364, rank * M)
-    left_w = args.warmup
-    while left_w > 0:
-        if s.steps_done >= L:
-            batch += 1
-            s.init_replicas(M, 82364, (batch * world + rank) * M)
-        left_w -= s.run_steps(min(left_w, L - s.steps_done))
-
-    # ---- timed region: exactly K steps ----
-    sync_all()
-    dev_ms, launches = 0.0, 0
+    # ---- one COMPLETE anneal, untimed by the metric: models for the parity keys, wall-clock per chromosome ----
+    s.init_replicas(M, 82364, 10 ** 6 + first)
+    s.run_steps(L)                                # first pass: builds whatever the full schedule needs
+    s.init_replicas(M, 82364, first)
     t0 = time.perf_counter()
-    left = args.steps
-    finished = None
-    while left > 0:
-        if s.steps_done >= L:
-            if finished is None:
-                finished = (s.coords(), s.energies(), batch)     # a complete schedule: keep for scoring
-            batch += 1
-            s.init_replicas(M, 82364, (batch * world + rank) * M)
-        done = s.run_steps(min(left, L - s.steps_done))           # synchronises the solver stream
-        ms, _, la = s.last_timing()
-        dev_ms += ms
-        launches += la
-        left -= done
-    sync_all()
-    wall = time.perf_counter() - t0
+    s.run_steps(L)
+    full_wall = time.perf_counter() - t0
+    full_dev_ms = s.last_timing()[0]
+    xyz = s.coords()
+    en = s.energies()
+    xyz = xyz - xyz.mean(axis=1, keepdims=True)
+
+    # ---- the benchmark's call pattern: init, W warm-up steps, `reps` regions of K steps -----------------------
+    def pattern(timed):
+        batch = 0
+        s.init_replicas(M, 82364, first)
+        left_w = args.warmup
+        while left_w > 0:
+            if s.steps_done >= L:
+                batch += 1
+                s.init_replicas(M, 82364, batch * total_replicas + first)
+            left_w -= s.run_steps(min(left_w, L - s.steps_done))
+        walls, devs, launches = [], [], 0
+        for _ in range(reps):
+            if timed:
+                sync_all()
+            t0 = time.perf_counter()
+            left, dev = args.steps, 0.0
+            while left > 0:
+                if s.steps_done >= L:
+                    batch += 1
+                    s.init_replicas(M, 82364, batch * total_replicas + first)
+                left -= s.run_steps(min(left, L - s.steps_done))      # synchronises the solver stream
+                ms, _, la = s.last_timing()
+                dev += ms
+                launches += la
+            if timed:
+                sync_all()
+            walls.append(time.perf_counter() - t0)
+            devs.append(dev)
+        return walls, devs, launches
+
+    pattern(False)                                # untimed: every graph the pattern needs exists afterwards
+    cap0 = s.stat("graph_captures")
+    fb0 = s.stat("resident_fallbacks")
+    walls, devs, launches = pattern(True)
+    captures_in_timed = s.stat("graph_captures") - cap0
+    assert captures_in_timed == 0, f"{captures_in_timed} hipGraph captures inside the timed regions"
+    kernel = s.step_kernel_name
+    path = int(s.stat("last_path"))
+
     if dist is not None:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms_max = float(t[0]), float(t[1])
+        t = torch.tensor([walls, devs], dtype=torch.float64, device="cuda" if on_gpu_group else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # per region: the slowest rank
+        walls, devs = t[0].tolist(), t[1].tolist()
+        fw = torch.tensor([full_wall, full_dev_ms, float(M)], dtype=torch.float64, device="cuda" if on_gpu_group else "cpu")
+        allfw = [torch.zeros_like(fw) for _ in range(world)]
+        dist.all_gather(allfw, fw)
+        full_wall = max(float(a[0]) for a in allfw)
+        full_dev_ms = max(float(a[1]) for a in allfw)
+        per_rank = [int(a[2]) for a in allfw]
     else:
-        dev_ms_max = dev_ms
-    if s.steps_done >= L and finished is None:
-        finished = (s.coords(), s.energies(), batch)
+        per_rank = [M]
+    wall = statistics.median(walls)
+    dev_ms = statistics.median(devs)
 
     # ---- scoring + the one collective (not timed) ----
-    extra = {}
-    if finished is not None:
-        xyz, en, b = finished
-        xyz = xyz - xyz.mean(axis=1, keepdims=True)
-        rho = pipeline.spearman_IF_models(IF, xyz)
-        ids = (b * world + rank) * M + np.arange(M)
-        rec = sharding.pack_records(ids, en[:, 0], rho, xyz)
-        tg = time.perf_counter()
-        allrec = sharding.gather_records(rec, device="cuda" if dist is not None and dist.get_backend() == "nccl" else None)
-        extra["gather_ms"] = round(1e3 * (time.perf_counter() - tg), 3)
-        order = sharding.rank_models(allrec)
-        extra["models_ranked"] = len(order)
-        extra["spearman_if_invd_best_ranked"] = round(-float(allrec[order[0], 2]), 4)
-        extra["spearman_if_invd_mean"] = round(-float(allrec[:, 2].mean()), 4)
-        extra["spearman_reference_model"] = 0.8722
-        extra["e_noe_best"] = round(float(allrec[order[0], 1]), 1)
+    rho = pipeline.spearman_IF_models(IF, xyz) if M > 0 else np.zeros(0)
+    rec = sharding.pack_records(first + np.arange(M), en[:, 0], rho, xyz)
+    tg = time.perf_counter()
+    allrec = sharding.gather_records(rec, device="cuda" if on_gpu_group else None)
+    gather_ms = 1e3 * (time.perf_counter() - tg)
+    order = sharding.rank_models(allrec)
 
     if rank == 0:
-        value = M * world * args.steps / wall
-        avg_launch_us = 1e3 * dev_ms_max / max(launches, 1)
-        bytes_per_launch = M * (4 * R + 72 * n)
-        achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9
+        value = total_replicas * args.steps / wall
+        B = 4 * R + 72 * n                                             # algorithmic bytes per replica-step
+        us_per_step_dev = 1e3 * dev_ms / args.steps
+        launches_per_region = launches / reps
+        bytes_per_launch = M * B * args.steps / max(launches_per_region, 1e-9)
+        avg_launch_us = 1e3 * dev_ms / max(launches_per_region, 1e-9)
+        achieved = M * B / (us_per_step_dev * 1e-6) / 1e9              # this rank's GPU: its replicas' bytes per device second
+        traffic, traffic_src = hbm_traffic_from_profiles(kernel, n, M)
         out = {
-            "metric": "SA-steps/sec (replica-steps/s, 20 replicas per GPU of chr1_500kb); wall-clock per chromosome",
+            "metric": "SA-steps/sec (replica-steps/s, 20 replicas of chr1_500kb); wall-clock per chromosome",
             "value": round(value, 1),
             "unit": "replica-steps/s",
             "n_gpus": world,
@@ -223,32 +264,46 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * wall / args.steps, 6),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "bundled Hi-C matrix chr1_500kb (tests/golden/inputs, exact float64 upper triangle); random-coil starts, seed 82364",
-            "config": {"workload": f"{WORKLOAD}: N={n} beads, R={R} restraints, {M} replicas per GPU, default schedule "
+            "config": {"workload": f"{WORKLOAD}: N={n} beads, R={R} restraints, {total_replicas} replicas in all "
+                                   f"({'+'.join(str(c) for c in per_rank)} per GPU), default schedule "
                                    f"(200 FIRE + 1000 hot MD + 972 cool MD + {MIN_STEPS} FIRE = {L} SA steps)",
-                       "replicas_per_gpu": M, "parallelism": f"replica-sharded x{world}",
-                       "launch": "eager" if args.no_graph else "hipGraph"},
-            "wall_s_per_chromosome_20_replicas": round(L * wall / args.steps, 4),
-            "device_ms_timed_region": round(dev_ms_max, 3),
+                       "replicas_per_gpu": per_rank, "parallelism": f"replica-sharded x{world}",
+                       "launch": {2: "one multi-step cluster launch per region", 0: "eager" if args.no_graph else "hipGraph"}.get(path, "?")},
+            "reps": reps,
+            "region_wall_ms": {"median": round(1e3 * wall, 4), "min": round(1e3 * min(walls), 4), "max": round(1e3 * max(walls), 4)},
+            "device_ms_per_region": round(dev_ms, 4),
+            "us_per_step_device": round(us_per_step_dev, 4),
+            "graph_captures_in_timed_regions": int(captures_in_timed),
+            "multi_step_launches_abandoned": int(s.stat("resident_fallbacks") - fb0),
+            "wall_s_per_chromosome_full_schedule": round(full_wall, 5),
+            "device_ms_full_schedule": round(full_dev_ms, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": 3.9e6 * M / 20 if n == 455 else None,
-                         "traffic_source": "profiles/r01_pmc_hbm_traffic_k_step.txt (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
-                         "kernel": "c3d::k_step<1,false,2>", "avg_launch_us": round(avg_launch_us, 3),
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "B = 4R + 72N per replica-step (SURVEY 8d) x replicas per SA step; duration = HIP-event time of "
-                                 "the timed region / SA steps (one step = one k_step launch per replica group, the groups "
-                                 "overlap on two streams); the 0.93 MB target matrix is shared by the replicas and stays in "
-                                 "L2, so fabric traffic is below B by design"},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel, "avg_launch_us": round(avg_launch_us, 3),
+                         "launches_per_region": round(launches_per_region, 2),
+                         "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                         "algorithmic_bytes_per_sa_step": M * B,
+                         "note": "B = 4R + 72N per replica-step (SURVEY 8d) x replicas on this GPU; duration = HIP-event time of the "
+                                 "timed region (median) on the solver's stream; the kernel is VALU-issue bound (DESIGN 5), the target "
+                                 "matrix lives in registers / L2, so fabric traffic is below B by design"},
+            "gather_ms": round(gather_ms, 3),
+            "models_ranked": len(order),
+            "spearman_if_invd_best_ranked": round(-float(allrec[order[0], 2]), 4),
+            "spearman_if_invd_mean": round(-float(allrec[:, 2].mean()), 4),
+            "spearman_reference_model": 0.8722,
+            "e_noe_best": round(float(allrec[order[0], 1]), 1),
         }
-        out.update(extra)
         if not args.no_cpu_baseline:
             v, sample, all_cores = cpu_baseline(IF, d10, model, fire, stages)
             out["cpu_baseline"] = {"value": round(v, 1), "unit": "replica-steps/s", "cores": 1, "kind": "port",
-                                   "sample": sample, "all_cores": all_cores}
+                                   "sample": sample, "all_cores": all_cores,
+                                   "reference_cpu_note": "the reference's CNS leg cannot run here (BASELINE.md 4); its Perl front half "
+                                                         "took 3.3 s and its assessment 4.5 s per model at N=455 on one core (BASELINE.md 2)"}
         print(json.dumps(out), flush=True)
     s.close()
     if dist is not None:

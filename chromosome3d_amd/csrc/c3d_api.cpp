@@ -171,7 +171,7 @@ void free_replica_buffers(c3d_ctx* c) {
     c->have_replicas = false;
 }
 void drop_graphs(c3d_ctx* c) {
-    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
 }
 
@@ -372,77 +372,69 @@ int run_ops(c3d_ctx* c, size_t nops) {
     }
     c->last_path = 0;
     const int G = active_groups(c);
-    // eager: every replica group advances on its own stream (fork from / join into stream 0 around the range)
-    auto fork = [&]() -> int {
-        if (G > 1) {
-            HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
-            for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(c->gstream[g], c->fork_ev, 0));
-        }
-        return C3D_OK;
-    };
-    auto join = [&]() -> int {
-        for (int g = 1; g < G; ++g) {
-            HIP_TRY(hipEventRecord(c->gev[g], c->gstream[g]));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->gev[g], 0));
-        }
-        return C3D_OK;
-    };
-    auto launch_chunk = [&](size_t chunk) -> int {
-        for (int g = 0; g < G; ++g) {
-            int par = c->parity;
-            for (size_t k = 0; k < chunk; ++k) {
-                int rc = launch_op(c, c->program[c->pc + k], g, par);
-                if (rc) return rc;
-                par ^= 1;
-            }
-        }
-        c->step_launches += (long)chunk * G;
-        return C3D_OK;
-    };
+    // every replica group advances on its own stream (fork from / join into stream 0 around the range): while one
+    // group sits in its launch boundary the other computes
+    if (G > 1) {
+        HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
+        for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(c->gstream[g], c->fork_ev, 0));
+    }
     size_t done = 0;
     while (done < nops) {
         const size_t chunk = std::min<size_t>(nops - done, c->use_graph ? (size_t)c->graph_chunk : nops - done);
-        int rc;
         if (!c->use_graph || chunk < 4) {
-            if ((rc = fork()) || (rc = launch_chunk(chunk)) || (rc = join())) return rc;
+            for (int g = 0; g < G; ++g) {
+                int par = c->parity;
+                for (size_t k = 0; k < chunk; ++k) {
+                    int rc = launch_op(c, c->program[c->pc + k], g, par);
+                    if (rc) return rc;
+                    par ^= 1;
+                }
+            }
         } else {
-            // ONE graph holds the chunk of every replica group (the groups are parallel branches of it): one
-            // hipGraphLaunch per chunk.  Homogeneous FIRE ranges (same stage, all kind 2) share a graph regardless of pc.
+            // one graph per (range, parity, group); homogeneous FIRE ranges (same stage, all kind 2) share a graph
+            // regardless of pc
             const Op& first = c->program[c->pc];
             const Op& last = c->program[c->pc + chunk - 1];
             long sig = (long)c->pc;
             if (first.p.kind == 2 && last.p.kind == 2 && first.stage == last.stage) sig = -(long)(first.stage + 1);
-            const auto key = std::make_tuple(sig, (int)chunk, c->parity, G);
-            auto it = c->graphs.find(key);
-            if (it == c->graphs.end()) {
-                if (c->graphs.size() >= 1024) drop_graphs(c);      // bounded: a caller with ever new ranges starts over
-                hipGraph_t gr = nullptr;
-                HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                rc = fork();
-                const long before = c->step_launches;
-                if (!rc) rc = launch_chunk(chunk);
-                c->step_launches = before;                           // captured, not launched
-                if (!rc) rc = join();
-                hipError_t ce = hipStreamEndCapture(c->stream, &gr);
-                if (rc) { if (gr) hipGraphDestroy(gr); return rc; }
-                if (ce != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-                hipGraphExec_t ge = nullptr;
-                hipError_t ie = hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0);
-                hipGraphDestroy(gr);
-                if (ie != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
-                it = c->graphs.emplace(key, ge).first;
-                ++c->graph_captures;
+            if (c->graphs.size() >= 2048) {                        // bounded: a caller with ever new ranges starts over
+                for (int g = 0; g < G; ++g) HIP_TRY(hipStreamSynchronize(c->gstream[g]));
+                drop_graphs(c);
             }
-            HIP_TRY(hipGraphLaunch(it->second, c->stream));
-            ++c->graph_launches;
-            c->step_launches += (long)chunk * G;
+            for (int g = 0; g < G; ++g) {
+                const auto key = std::make_tuple(sig, (int)chunk, c->parity, g);
+                auto it = c->graphs.find(key);
+                if (it == c->graphs.end()) {
+                    hipGraph_t gr = nullptr;
+                    HIP_TRY(hipStreamBeginCapture(c->gstream[g], hipStreamCaptureModeThreadLocal));
+                    int par = c->parity;
+                    int rc = C3D_OK;
+                    for (size_t k = 0; k < chunk && rc == C3D_OK; ++k) { rc = launch_op(c, c->program[c->pc + k], g, par); par ^= 1; }
+                    hipError_t ce = hipStreamEndCapture(c->gstream[g], &gr);
+                    if (rc) { if (gr) (void)hipGraphDestroy(gr); return rc; }
+                    if (ce != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+                    hipGraphExec_t ge = nullptr;
+                    hipError_t ie = hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(gr);
+                    if (ie != hipSuccess) return fail(C3D_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+                    it = c->graphs.emplace(key, ge).first;
+                    ++c->graph_captures;
+                }
+                HIP_TRY(hipGraphLaunch(it->second, c->gstream[g]));
+                ++c->graph_launches;
+            }
         }
+        c->step_launches += (long)chunk * G;
         if (chunk & 1) c->parity ^= 1;
         for (size_t k = 0; k < chunk; ++k)
             if (c->program[c->pc + k].counted) { ++c->steps_done; ++c->last_steps; }
         c->last_launches += (long)chunk;
         c->pc += chunk;
         done += chunk;
+    }
+    for (int g = 1; g < G; ++g) {
+        HIP_TRY(hipEventRecord(c->gev[g], c->gstream[g]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->gev[g], 0));
     }
     return C3D_OK;
 }
