@@ -19,13 +19,21 @@ use File::Basename;
 use File::Copy;
 use Getopt::Long;
 
-my ($help, $dir_out, $file_if);
+my ($help, $dir_out, $file_if, $shape_only);
 my ($K, $ALPHA, $MODELS) = (11, 0.5, 20);        # chromosome3D.pl:18-21
 my ($SEED, $DEVICE, $DISTRELAX) = (82364, 0, 0.5);  # :980, :74
 GetOptions("h" => \$help, "o=s" => \$dir_out, "k=i" => \$K, "a=s" => \$ALPHA, "m=i" => \$MODELS,
-           "i|if=s" => \$file_if, "seed=i" => \$SEED, "device=i" => \$DEVICE)
+           "i|if=s" => \$file_if, "seed=i" => \$SEED, "device=i" => \$DEVICE, "shape=s" => \$shape_only)
 	or die "ERROR! Error in command line arguments!\n";
 usage() if $help;
+# residue names a model row may carry (the 20 standard amino acids; rows with any other name are dropped, reference :847)
+my %AA = map { $_ => 1 } qw(ALA ASN CYS GLN HIS LEU MET PRO THR TYR ARG ASP GLU GLY ILE LYS PHE SER TRP VAL);
+if (defined $shape_only) {   # test hook: only the output shaping of one solver PDB, in place (no GPU involved)
+	open my $lg, ">>", ($dir_out // ".")."/model_info.log" or die $!;
+	shape_pdb($shape_only, $lg);
+	close $lg;
+	exit 0;
+}
 usage("Input IF matrix not found!") if not defined $file_if;
 usage("Output directory not defined!") if not defined $dir_out;
 usage("Input IF file $file_if does not exist!") if not -f $file_if;
@@ -124,8 +132,10 @@ foreach my $pdb (sort { $e_noe{$b} <=> $e_noe{$a} || $a cmp $b } keys %e_noe) {
 	print $vf "$_\n" foreach (@viol, @ok);
 	close $vf;
 	printf "%-9s             %-9s                %-25s\n", "$count/$total", (sprintf "%.2f", $sum_dev), basename($pdb, ".pdb");
-	print $log "$pdb\n".join("", grep { /^REMARK/ } do { open my $f, "<", $pdb or die $!; <$f> })."\n";
 }
+print "\n";
+print "removing non-CA ATOM rows and backing up REMARK rows..\n";
+shape_pdb($_, $log) foreach (sort { $e_noe{$b} <=> $e_noe{$a} || $a cmp $b } keys %e_noe);
 close $log;
 print "\n";
 my $rank = 1;
@@ -136,6 +146,34 @@ foreach my $pdb (sort { $e_noe{$a} <=> $e_noe{$b} || $a cmp $b } keys %e_noe) {
 }
 print "\nFinished [$0]: ".(localtime)."\n";
 
+# Output shaping of one model, in place — what the reference's assess_dgsa leaves behind (:813-820): REMARK rows go to
+# model_info.log behind the file name; ATOM rows that mention CA stay, atoms and residues renumbered from 1,
+# chain id blanked; an empty line (the reference writes END there and then deletes the word); CONECT i i+1; END.
+sub shape_pdb {
+	my ($pdb, $logfh) = @_;
+	open my $in, "<", $pdb or die "ERROR! cannot read $pdb: $!\n";
+	my @rows = <$in>;
+	close $in;
+	print $logfh $pdb;   # the reference's log has the name glued to the first REMARK row (print2line, :870)
+	my ($atoms, $res, $prev, $nca, @out) = (0, 0, "XX", 0);
+	foreach my $r (@rows) {
+		print $logfh $r if $r =~ /^REMARK/;
+		next if $r !~ /^ATOM/ or $r !~ /CA/;
+		my ($alt, $rname, $rnum, $aname) = map { (my $t = length($r) > $_->[0] ? substr($r, $_->[0], $_->[1]) : "") =~ s/\s+//g; $t } ([16, 1], [17, 3], [22, 5], [12, 4]);
+		next if not ($alt eq "" or $alt eq "A");
+		next if not exists $AA{$rname};
+		if ($rnum ne $prev) { $prev = $rnum; $res++; }
+		$atoms++;
+		$nca++ if $aname eq "CA";
+		push @out, substr($r, 0, 6).sprintf("%5s", $atoms).substr($r, 11, 5)." ".substr($r, 17, 3)."  ".sprintf("%4s", $res)." ".substr($r, 27);
+	}
+	die "ERROR! $pdb has less than 1 residue!\n" if $nca < 1;
+	open my $o, ">", $pdb or die "ERROR! cannot write $pdb: $!\n";
+	print $o @out, "\n";
+	printf $o "CONECT%5s%5s\n", $_, $_ + 1 foreach (1 .. $nca - 1);
+	print $o "END\n";
+	close $o;
+}
 sub first_line_fields { open my $f, "<", shift or die $!; my $l = <$f>; close $f; $l =~ s/^\s+//; my @t = split /\s+/, $l; return scalar @t; }
 sub read_tbl {
 	my @rows;

@@ -186,6 +186,9 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
     m.rs = h.rswitch;
     m.tail_c = h.asym * h.rswitch;
     m.tail_b = (m.tail_c - 2.0f * h.rswitch) * h.rswitch * h.rswitch;
+    m.mrs = h.mrswitch; m.nmrs = -h.mrswitch;
+    m.mtail_c = h.masym;
+    m.mtail_b = (m.mtail_c - 2.0f * h.mrswitch) * h.mrswitch * h.mrswitch;
     m.k_bond2 = 2.0f * h.k_bond; m.b0 = h.b0;
     m.k_ang2 = 2.0f * h.k_ang; m.a0 = h.a0;
     m.acc = c3d::kAccel / h.mass;
@@ -195,7 +198,11 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
     m.inv_n = 1.0f / (float)c->n;
     return m;
 }
-bool general_tail(const c3d::DevModel& m) { return !(m.tail_b == 0.0f && m.tail_c == 2.0f * m.rs); }
+// default tails: the force stays at its value at the switch distance (slope 2 rs above, 2 mrs below for noe_pot 3)
+bool general_tail(const c3d::DevModel& m) {
+    if (!(m.tail_b == 0.0f && m.tail_c == 2.0f * m.rs)) return true;
+    return m.noe_pot == 3 && !(m.mtail_b == 0.0f && m.mtail_c == 2.0f * m.mrs);
+}
 c3d::DevFire dev_fire(const c3d_ctx* c) {
     c3d::DevFire f;
     f.dt_start = c->fire.dt_start; f.dt_max = c->fire.dt_max; f.f_inc = c->fire.f_inc; f.f_dec = c->fire.f_dec;
@@ -491,12 +498,15 @@ extern "C" int c3d_device_count(void) {
 
 extern "C" void c3d_default_model(c3d_model* m) {
     if (!m) return;
-    m->min_sep = 5; m->noe_pot = 1; m->rep_sep = 2; m->ang_mode = 1;
+    m->min_sep = 5; m->noe_pot = 3; m->rep_sep = 2; m->ang_mode = 1;
     m->s_noe = 10.0f; m->rswitch = 1.0f; m->asym = 2.0f;
     m->k_bond = 700.0f; m->b0 = 3.8f;
     m->k_ang = 80.0f; m->a0 = 7.4f;
     m->r0_rep = 6.75f; m->k_rep = 1.0f;
     m->mass = 100.0f; m->fbeta = 10.0f;
+    // lower side of the NOE term: the force stops growing once a pair sits more than mrswitch inside its target
+    // (calibrated on the 45 bundled models; slope 2 mrswitch = no 1/D^2 term)
+    m->mrswitch = 11.0f; m->masym = 22.0f;
 }
 extern "C" void c3d_default_fire(c3d_fire_params* f) {
     if (!f) return;
@@ -595,7 +605,7 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
 
 extern "C" int c3d_set_model(c3d_ctx* c, const c3d_model* m) {
     if (!c || !m) return fail(C3D_ERR_INVALID, "c3d_set_model: null argument");
-    if (m->mass <= 0 || m->rswitch <= 0 || m->min_sep < 1 || m->rep_sep < 1 || m->rep_sep > 3 || m->noe_pot < 0 || m->noe_pot > 2)
+    if (m->mass <= 0 || m->rswitch <= 0 || m->min_sep < 1 || m->rep_sep < 1 || m->rep_sep > 3 || m->noe_pot < 0 || m->noe_pot > 3 || m->mrswitch <= 0)
         return fail(C3D_ERR_INVALID, "c3d_set_model: parameter out of range");
     if (c->have_targets && m->min_sep != c->model.min_sep)
         return fail(C3D_ERR_INVALID, "c3d_set_model: min_sep must be set before the targets are built");

@@ -395,6 +395,7 @@ hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPla
     switch (m.noe_pot) {
         case 0: return cluster_geom<0>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
         case 1: return cluster_geom<1>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
+        case 3: return cluster_geom<3>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
         default: return cluster_geom<2>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
     }
 }

@@ -269,6 +269,78 @@ extern "C" int c3d_write_pdb(const char* path, const float* xyz, int n, double e
     return C3D_OK;
 }
 
+// A16 (chromosome3D.pl:813-820): filter_nonCA :864-880, reindex_chain :831-862, sed :818, add_connect_rows :208-215
+extern "C" int c3d_shape_pdb(const char* in_path, const char* out_path, const char* log_path) {
+    if (!in_path || !out_path) return fail(C3D_ERR_INVALID, "c3d_shape_pdb: null argument");
+    std::string txt;
+    if (!read_file(in_path, txt)) return fail(C3D_ERR_IO, std::string("cannot read ") + in_path);
+    static const char* kResidues[] = {"ALA", "ASN", "CYS", "GLN", "HIS", "LEU", "MET", "PRO", "THR", "TYR",
+                                      "ARG", "ASP", "GLU", "GLY", "ILE", "LYS", "PHE", "SER", "TRP", "VAL"};   // %AA3TO1, :77
+    auto field = [](const std::string& row, size_t pos, size_t len) {   // Perl substr + s/\s+//g
+        std::string f = pos < row.size() ? row.substr(pos, len) : std::string();
+        f.erase(std::remove_if(f.begin(), f.end(), [](char ch) { return is_ws(ch); }), f.end());
+        return f;
+    };
+    std::string log = std::string(in_path), body;   // print2line :870 writes the name without a line end
+    std::string prev_rnum = "XX";
+    int res_counter = 0, atom_counter = 0, n_ca = 0;
+    size_t p = 0;
+    while (p < txt.size()) {
+        size_t e = txt.find('\n', p);
+        const bool had_nl = e != std::string::npos;
+        if (!had_nl) e = txt.size();
+        const std::string row = txt.substr(p, e - p);
+        p = e + 1;
+        if (row.compare(0, 6, "REMARK") == 0) log += row + "\n";                 // filter_nonCA :873
+        if (row.compare(0, 4, "ATOM") != 0) continue;                              // :874
+        if (row.find("CA") == std::string::npos) continue;                         // :875 (the whole row is searched)
+        // reindex_chain: alternative locations other than "" / "A" and unknown residue names are dropped (:846-847)
+        const std::string alt = field(row, 16, 1);
+        if (!(alt.empty() || alt == "A")) continue;
+        const std::string rname = field(row, 17, 3);
+        bool known = false;
+        for (const char* r : kResidues) known = known || rname == r;
+        if (!known) continue;
+        const std::string rnum = field(row, 22, 5);
+        if (rnum != prev_rnum) { prev_rnum = rnum; ++res_counter; }
+        ++atom_counter;
+        if (field(row, 12, 4) == "CA") ++n_ca;                                     // seq_chain counts CA atoms (:222)
+        char num[32];
+        std::string out = row.substr(0, 6);
+        snprintf(num, sizeof num, "%5d", atom_counter);
+        out += num;
+        out += row.size() > 11 ? row.substr(11, 5) : std::string();
+        out += " ";
+        out += row.size() > 17 ? row.substr(17, 3) : std::string();
+        out += "  ";
+        snprintf(num, sizeof num, "%4d", res_counter);
+        out += num;
+        out += " ";
+        if (row.size() > 27) out += row.substr(27);
+        body += out + "\n";
+    }
+    if (n_ca < 1) return fail(C3D_ERR_IO, std::string(in_path) + " has less than 1 residue");   // seq_chain :231
+    body += "\n";                                                                  // "END" written by :860, emptied by the sed of :818
+    for (int i = 1; i < n_ca; ++i) {
+        char row[32];
+        snprintf(row, sizeof row, "CONECT%5d%5d\n", i, i + 1);
+        body += row;
+    }
+    body += "END\n";
+    // the sed of :818 removes the three letters wherever they stand
+    if (log_path) {
+        FILE* lf = fopen(log_path, "a");
+        if (!lf) return fail(C3D_ERR_IO, std::string("cannot append to ") + log_path);
+        fwrite(log.data(), 1, log.size(), lf);   // :879 appends an empty string
+        fclose(lf);
+    }
+    FILE* f = fopen(out_path, "w");
+    if (!f) return fail(C3D_ERR_IO, std::string("cannot write ") + out_path);
+    fwrite(body.data(), 1, body.size(), f);
+    fclose(f);
+    return C3D_OK;
+}
+
 extern "C" int c3d_read_pdb_ca(const char* path, float** xyz, int* n_out) {
     if (!path || !xyz || !n_out) return fail(C3D_ERR_INVALID, "c3d_read_pdb_ca: null argument");
     std::string txt;

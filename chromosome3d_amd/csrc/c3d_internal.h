@@ -25,6 +25,8 @@ struct DevModel {
     int rpw;                       // rows per wave of the step kernel (1, 2 or 4); waves/WG = kTileRows/rpw
     int noe_pot, ang_mode, rep_sep;
     float rs, tail_c, tail_b;      // soft tail: dE/dD = tail_c - tail_b / D^2  (D > rs)
+    float mrs, mtail_c, mtail_b;   // noe_pot 3, lower side: dE/dD = mtail_c - mtail_b / D^2  (D = t - d > mrs)
+    float nmrs;                    // -mrs
     float k_bond2, b0;             // 2*k_bond
     float k_ang2, a0;              // 2*k_ang
     float acc;                     // kAccel / mass

@@ -86,15 +86,17 @@ __device__ __forceinline__ float reduce_rows(const float (&a)[RPW], int lane) {
 
 template <int POT, bool GEN>
 __device__ __forceinline__ float noe_grad(float delta, const DevModel& m) {
-    if constexpr (!GEN) {  // tail slope == 2*rs, b == 0: the CNS defaults
+    if constexpr (!GEN) {  // tail slope == 2*rs (and 2*mrs on the lower side of POT 3), b == 0
         if constexpr (POT == 1) return 2.0f * fminf(delta, m.rs);
         else if constexpr (POT == 0) return 2.0f * fminf(fmaxf(delta, -m.rs), m.rs);
+        else if constexpr (POT == 3) return 2.0f * fminf(fmaxf(delta, -m.mrs), m.rs);
         else return 2.0f * delta;
     } else {
         const float ad = fabsf(delta);
         const float tail = m.tail_c - m.tail_b / (ad * ad);
         if constexpr (POT == 1) return delta > m.rs ? tail : 2.0f * delta;
         else if constexpr (POT == 0) return ad > m.rs ? copysignf(tail, delta) : 2.0f * delta;
+        else if constexpr (POT == 3) return delta > m.rs ? tail : (delta < -m.mrs ? m.mtail_b / (ad * ad) - m.mtail_c : 2.0f * delta);
         else return 2.0f * delta;
     }
 }
@@ -137,6 +139,7 @@ __device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, f
         if constexpr (RS1) lim = rinv; else lim = m.rs * rinv;
         if constexpr (POT == 1) s = fminf(u, lim);
         else if constexpr (POT == 0) s = fminf(fmaxf(u, -lim), lim);
+        else if constexpr (POT == 3) s = __builtin_amdgcn_fmed3f(u, m.nmrs * rinv, lim);   // clamp(u, -mrs/d, rs/d): one v_med3_f32
         else s = u;
     } else {
         s = 0.5f * noe_grad<POT, GEN>(r2 * rinv - v, m) * rinv;

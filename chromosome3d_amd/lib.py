@@ -22,7 +22,7 @@ class Model(C.Structure):
     _fields_ = [("min_sep", C.c_int32), ("noe_pot", C.c_int32), ("rep_sep", C.c_int32), ("ang_mode", C.c_int32),
                 ("s_noe", C.c_float), ("rswitch", C.c_float), ("asym", C.c_float),
                 ("k_bond", C.c_float), ("b0", C.c_float), ("k_ang", C.c_float), ("a0", C.c_float),
-                ("r0_rep", C.c_float), ("k_rep", C.c_float), ("mass", C.c_float), ("fbeta", C.c_float)]
+                ("r0_rep", C.c_float), ("k_rep", C.c_float), ("mass", C.c_float), ("fbeta", C.c_float), ("masym", C.c_float), ("mrswitch", C.c_float)]
 
 
 class Stage(C.Structure):
@@ -79,6 +79,7 @@ SIGNATURES = {
     "c3d_write_front_half": (_i, [_i32p, _i, _i, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_i)]),
     "c3d_read_tbl": (_i, [C.c_char_p, C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_i)]),
     "c3d_write_pdb": (_i, [C.c_char_p, _fp, _i, _d, _d, _d, C.c_char_p]),
+    "c3d_shape_pdb": (_i, [C.c_char_p, C.c_char_p, C.c_char_p]),
     "c3d_read_pdb_ca": (_i, [C.c_char_p, C.POINTER(_fp), C.POINTER(_i)]),
     "c3d_assess": (_i, [_fp, _i, _i, _i32p, _i32p, _i32p, _d, C.POINTER(_i), _dp]),
     "c3d_spearman_if_dist": (_i, [_dp, _fp, _i, _i, _dp]),

@@ -86,6 +86,12 @@ def write_pdb(path, xyz, e_noe=0.0, e_bond=0.0, e_rep=0.0, title=None):
                                      title.encode() if title else None))
 
 
+def shape_pdb(in_path, out_path=None, log_path=None):
+    """A16: filter_nonCA + reindex_chain + sed + add_connect_rows (:813-820) — the file assess_dgsa leaves behind."""
+    _l.check(_l.load().c3d_shape_pdb(os.fsencode(in_path), os.fsencode(out_path or in_path),
+                                     os.fsencode(log_path) if log_path else None))
+
+
 def read_pdb_ca(path):
     L = _l.load()
     p = C.POINTER(C.c_float)()
@@ -156,7 +162,8 @@ def build_models(solver, model_count=MODELCOUNT, seed=MD_SEED, first_replica=0, 
 
 def assess_dgsa(out_dir, ID, xyz, energies, rows, top=5):
     """Rank by int(E_noe) ascending (:796-802), print the satisfaction table (:804-810), write every
-    model as <ID>_<k>.pdb and rename the best `top` to <ID>_model<i>.pdb (:822-828)."""
+    model as <ID>_<k>.pdb, shape it as :813-820 does (CA rows renumbered, CONECT, REMARKs to model_info.log)
+    and rename the best `top` to <ID>_model<i>.pdb (:822-828)."""
     M = xyz.shape[0]
     order = sorted(range(M), key=lambda r: (int(energies[r, 0]), r))
     report = []
@@ -170,6 +177,8 @@ def assess_dgsa(out_dir, ID, xyz, energies, rows, top=5):
         report.append((r, sat, dev))
         print("%-9s             %-9s                %-25s" % (f"{sat}/{len(rows[0])}", "%.2f" % dev,
                                                               os.path.basename(names[r])[:-4]))
+    for r in reversed(order):
+        shape_pdb(names[r], None, os.path.join(out_dir, "model_info.log"))
     for k, r in enumerate(order[:top]):
         dst = os.path.join(out_dir, f"{ID}_model{k + 1}.pdb")
         os.replace(names[r], dst)

@@ -43,7 +43,8 @@ typedef struct c3d_ctx c3d_ctx;
  * con_wt chromosome3D.pl:66,1111,1120; mass/fbeta :1415-1416; SEPARATION :20. */
 typedef struct {
     int32_t min_sep;   /* 5: restraints only for |i-j| >= min_sep                        */
-    int32_t noe_pot;   /* 0 symmetric soft-square, 1 X-PLOR soft-square (default), 2 square */
+    int32_t noe_pot;   /* 0 symmetric soft-square, 1 X-PLOR soft-square (default), 2 square,
+                          3 CNS soft-square with a soft LOWER side too (slope masym beyond mrswitch) */
     int32_t rep_sep;   /* repel acts on |i-j| >= rep_sep (1..3)                          */
     int32_t ang_mode;  /* (i,i+2) term: 0 lower bound only, 1 harmonic                   */
     float s_noe;       /* NOE scale = con_wt = 10                                        */
@@ -55,6 +56,8 @@ typedef struct {
     float k_rep;       /* bead-level repel multiplier                                    */
     float mass;        /* 100 amu                                                        */
     float fbeta;       /* 10 /ps                                                         */
+    float masym;       /* noe_pot 3: asymptote slope of the lower side (CNS masymptote)  */
+    float mrswitch;    /* noe_pot 3: the lower side is square up to t - d = mrswitch     */
 } c3d_model;
 
 /* One stage of the annealing schedule (defaults: c3d_default_schedule, which restates
@@ -175,6 +178,12 @@ int c3d_read_tbl(const char* path, int32_t** ri, int32_t** rj, int32_t** rt10, i
 int c3d_write_pdb(const char* path, const float* xyz, int n, double e_noe, double e_bond, double e_rep,
                   const char* title);
 int c3d_read_pdb_ca(const char* path, float** xyz, int* n);
+/* A16, what assess_dgsa does to every solver-output PDB before it ranks them (chromosome3D.pl:813-820): filter_nonCA
+ * :864-880 (REMARK rows go to `log_path`, appended after a line with the input path; ATOM rows containing "CA" stay),
+ * reindex_chain :831-862 (atoms and residues renumbered from 1, chain id blanked), `sed -i "s/END//g"` :818 (the END row
+ * becomes an empty line), add_connect_rows :208-215 (CONECT i i+1, END).  `out_path` may equal `in_path`; `log_path` may
+ * be NULL.  The result is byte-identical to the file the reference leaves behind (tests/golden/output_side). */
+int c3d_shape_pdb(const char* in_path, const char* out_path, const char* log_path);
 /* chromosome3D.pl:447-485, 581-600 on coordinates rounded to 3 decimals as a PDB holds them */
 int c3d_assess(const float* xyz, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10,
                double relax, int* satisfied, double* sum_dev);

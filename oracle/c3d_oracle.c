@@ -237,6 +237,7 @@ typedef struct {
     double rswitch;   /* 1.0  CNS readdata default [CNS-UNVERIFIED] */
     double asym;      /* 2.0  asymptote slope      [CNS-UNVERIFIED] */
     double masym;     /* lower-side tail slope for noe_pot 3 (CNS masymptote) [CNS-UNVERIFIED] */
+    double mrswitch;  /* lower-side switch distance for noe_pot 3 (CNS mrswitch) [CNS-UNVERIFIED] */
     double k_bond;    /* pseudo-bond force constant (calibrated) */
     double b0;        /* 3.8 A */
     double r0_rep;    /* repel contact distance R0 (scaled by `repel` s) */
@@ -273,11 +274,12 @@ static inline double softsq(const c3o_model* m, double delta, double* e) {
     if (m->noe_pot == 0) soft = ad > rs;
     else if (m->noe_pot == 1) soft = delta > rs;
     else if (m->noe_pot == 3) {
-        if (delta < -rs) {   /* lower side: CNS minus-side soft form a + b/D + c D, c = masym
-                                (msoexponent 1, mrswitch = rswitch), C1-continuous at D = rs */
+        const double mrs = m->mrswitch;
+        if (delta < -mrs) {  /* lower side: CNS minus-side soft form a + b/D + c D, c = masym
+                                (msoexponent 1), C1-continuous at D = mrswitch */
             const double mc = m->masym;
-            const double mb = (mc - 2.0 * rs) * rs * rs;
-            const double ma = rs * rs - mb / rs - mc * rs;
+            const double mb = (mc - 2.0 * mrs) * mrs * mrs;
+            const double ma = mrs * mrs - mb / mrs - mc * mrs;
             *e += ma + mb / ad + mc * ad;
             return -(-mb / (ad * ad) + mc);
         }

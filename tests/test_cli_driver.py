@@ -92,12 +92,20 @@ def test_perl_driver_same_cli_and_outputs(built, tmp_path):
         pat = re.compile(r"^  [01]\t-?\d+\.\d\d\t\d+\.\d\d # assign45  resid +\d+ and name ca   resid +\d+ and name ca  \d+\.\d0 0\.00 0\.00$")
         assert pat.match(gold_fmt), gold_fmt
         assert all(pat.match(r) for r in vrows[2:530])
-        # ranking = ascending int(REMARK noe)
-        e = []
-        for m in models:
-            v = [l for l in open(m) if l.startswith("REMARK noe")][0].replace(" ", "").split("=")[1]
-            e.append(int(float(v)))
-        assert e == sorted(e)
+        # the final files are shaped as assess_dgsa leaves them (:813-820): ATOM rows, an empty line, CONECT rows, END;
+        # the REMARK rows went to model_info.log behind the file's name (reference :870-873)
+        for m in list(od.glob(f"{cid}_*.pdb")):
+            rows = open(m).read().split("\n")
+            assert all(r.startswith("ATOM") for r in rows[:37]) and rows[37] == "" and rows[38] == "CONECT    1    2"
+            assert rows[-2] == "END" and rows[-1] == "" and len(rows) == 37 + 1 + 36 + 2
+        log = open(od / "model_info.log").read()
+        noe = {m_.group(1): int(float(m_.group(2))) for m_ in re.finditer(r"\./(\S+?\.pdb)REMARK FILENAME.*?REMARK noe = ([-0-9.e+]+)", log, re.S)}
+        assert len(noe) == 7
+        # ranking = ascending int(REMARK noe) (:796-802, :822-828)
+        picked = [l.split("<=")[1].strip().lstrip("./") for l in out.stdout.splitlines() if re.match(r"model\d\.pdb <=", l)]
+        assert len(picked) == 5
+        e = [noe[pk] for pk in picked]
+        assert e == sorted(e) and max(e) <= min(v for k, v in noe.items() if k not in picked)
         # satisfaction table rows "count/528  sumdev  name" agree with the library's assessment
         from chromosome3d_amd import pipeline
         rows = pipeline.read_tbl(str(od / "contact.tbl"))

@@ -9,7 +9,7 @@ import numpy as np
 from scipy.optimize import minimize
 from chromosome3d_amd import Solver, default_model, default_schedule, default_fire, pipeline
 
-ALL = os.path.join(ROOT, "tests", "golden", "_all")
+ALL = os.path.join(ROOT, "tests", "golden", "all45")
 def load(cid):
     z = np.load(f"{ALL}/{cid}_upper.npz"); n = int(z["n"]); m = np.zeros((n, n)); iu = np.triu_indices(n)
     m[iu] = z["upper"]; m.T[iu] = z["upper"]; return m
@@ -29,6 +29,7 @@ s = Solver(0)
 NREP = 8
 def evaluate(params, names, subset):
     kw = dict(zip(names, params))
+    if "mrswitch" in kw: kw["masym"] = 2.0 * kw["mrswitch"]      # clamp-style lower tail
     d = []
     for c in subset:
         IF, ref = data[c]
@@ -43,9 +44,9 @@ def evaluate(params, names, subset):
         rho = -pipeline.spearman_IF_models(IF, x)
         d.append(rho[np.argmin(e[:, 0].astype(np.int64))] - ref)
     return np.array(d)
-names = ["k_bond", "k_ang", "a0", "r0_rep", "k_rep"]
-x0 = np.array([700.0, 80.0, 7.4, 6.75, 1.0])
-scale = np.array([200.0, 30.0, 0.3, 0.4, 0.5])
+names = ["k_bond", "k_ang", "a0", "r0_rep", "k_rep", "mrswitch"]
+x0 = np.array([700.0, 80.0, 7.4, 6.75, 1.0, 11.0])
+scale = np.array([200.0, 30.0, 0.3, 0.4, 0.5, 2.0])
 hist = []
 def obj(z):
     p = x0 + z * scale
@@ -57,7 +58,7 @@ def obj(z):
     return f
 maxev = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 t0 = time.time()
-res = minimize(obj, np.zeros(5), method="Nelder-Mead", options={"maxfev": maxev, "xatol": 0.05, "fatol": 2e-5, "initial_simplex": np.vstack([np.zeros(5), np.eye(5)])})
+res = minimize(obj, np.zeros(len(x0)), method="Nelder-Mead", options={"maxfev": maxev, "xatol": 0.05, "fatol": 2e-5, "initial_simplex": np.vstack([np.zeros(len(x0)), np.eye(len(x0))])})
 best = min(hist)[1]
 print("best train params", dict(zip(names, np.round(best, 3))), "in", round(time.time() - t0), "s")
 NREP = 20

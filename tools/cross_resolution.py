@@ -3,7 +3,7 @@
 way the reference's output_models/similarity.txt does (Spearman / scaled RMS of the pairwise distances).
 
     python tools/cross_resolution.py [replicas=20]
-Needs tests/golden/_all (tools/pack_all_inputs.py).  Prints a markdown table next to the reference's numbers
+Needs tests/golden/all45 (tools/pack_all_inputs.py).  Prints a markdown table next to the reference's numbers
 (tests/golden/similarity_reference.json).
 """
 import glob, json, os, re, sys
@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from chromosome3d_amd import Solver, default_model, default_schedule, default_fire, pipeline
 
-ALL = os.path.join(ROOT, "tests", "golden", "_all")
+ALL = os.path.join(ROOT, "tests", "golden", "all45")
 nrep = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ref = json.load(open(os.path.join(ROOT, "tests", "golden", "similarity_reference.json")))
 ref_by_chr = {re.match(r"(chr\d+)_", k).group(1): v for k, v in ref.items()}

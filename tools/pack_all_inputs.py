@@ -1,9 +1,9 @@
-"""Pack every bundled reference matrix + model into tests/golden/_all/ (git-ignored, travels with
+"""Pack every bundled reference matrix + model into tests/golden/all45/ (git-ignored, travels with
 gpurun snapshots) for the all-chromosome parity sweep.  Runs only where /root/reference exists."""
 import glob, os, shutil, sys
 import numpy as np
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "_all")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "all45")
 os.makedirs(OUT, exist_ok=True)
 for p in sorted(glob.glob(f"{REF}/input/*_matrix.txt")):
     cid = os.path.basename(p)[:-len("_matrix.txt")]

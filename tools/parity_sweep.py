@@ -2,7 +2,7 @@
 reference model of every chromosome, plus chain statistics.
 
     python tools/parity_sweep.py [json model overrides] [replicas=20] [subset regex]
-Needs tests/golden/_all (tools/pack_all_inputs.py; git-ignored data, present on the GPU box through
+Needs tests/golden/all45 (tools/pack_all_inputs.py; git-ignored data, present on the GPU box through
 the gpurun snapshot).  Prints a markdown table; the committed copy lives in profiles/.
 """
 import glob, json, os, re, sys, time
@@ -11,13 +11,14 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from chromosome3d_amd import Solver, default_model, default_schedule, default_fire, pipeline
 
-ALL = os.path.join(ROOT, "tests", "golden", "_all")
+ALL = os.path.join(ROOT, "tests", "golden", "all45")
 over = json.loads(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].startswith("{") else {}
 nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 subset = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
 min_steps = int(over.pop("min_steps", 3000))
 quiet = over.pop("quiet", 0)
 embed = over.pop("embed", 0)
+seed = int(over.pop("seed", 82364))
 
 def load(cid):
     z = np.load(f"{ALL}/{cid}_upper.npz"); n = int(z["n"]); m = np.zeros((n, n)); iu = np.triu_indices(n)
@@ -38,7 +39,7 @@ for cid in cids:
     s.set_model(default_model(**over))
     pipeline.IF2dist_new(s, IF)
     s.set_schedule(default_schedule(min_steps), default_fire(), 0.0, 250)
-    s.init_replicas(nrep, 82364, 0)
+    s.init_replicas(nrep, seed, 0)
     if embed:
         s.embed(50)
     s.run()

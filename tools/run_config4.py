@@ -6,7 +6,7 @@ Chromosomes are assigned to ranks by longest-processing-time-first on their rest
 (sharding.lpt_assign); every rank solves its chromosomes with 20 replicas each; one all_gather of the
 per-model records (RCCL on GPUs; C3D_BENCH_BACKEND=gloo for a rehearsal with fewer GPUs than ranks)
 brings everything to rank 0, which ranks the models per chromosome as chromosome3D.pl:796-802 does.
-Needs tests/golden/_all (tools/pack_all_inputs.py).  chr2_500kb is missing upstream (.MISSING_LARGE_BLOBS).
+Needs tests/golden/all45 (tools/pack_all_inputs.py).  chr2_500kb is missing upstream (.MISSING_LARGE_BLOBS).
 """
 import glob, os, re, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +23,7 @@ if world > 1:
     dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
 from chromosome3d_amd import Solver, default_model, default_schedule, pipeline, sharding
 
-ALL = os.path.join(ROOT, "tests", "golden", "_all")
+ALL = os.path.join(ROOT, "tests", "golden", "all45")
 cids = sorted((os.path.basename(p)[:-len("_upper.npz")] for p in glob.glob(f"{ALL}/*_500kb_upper.npz")),
               key=lambda c: int(re.match(r"chr(\d+)", c).group(1)))
 def load(cid):
