@@ -1,26 +1,10 @@
 #!/bin/bash
-# run_all_amd.sh — the reference's test.sh (test.sh:4-12: every chromosome at 1 Mb and 500 kb in the
-# background) for the MI355X driver: one job per matrix, round-robin over the GPUs of the node, at most
-# one job per GPU at a time (a 20-replica chromosome takes ~0.3 s end to end, so jobs are queued per GPU
-# rather than oversubscribed).
-#   bin/run_all_amd.sh <input dir with *_matrix.txt> <output root> [n_gpus=1] [extra driver options]
+# run_all_amd.sh — the reference's test.sh (test.sh:4-12: every chromosome at 1 Mb and 500 kb, one background
+# chromosome3D.pl per matrix) for the MI355X build: ONE c3d_batch process (chromosome3d_amd/csrc/c3d_batch_main.cpp),
+# one host thread and one libc3d context per GPU, matrices dealt to the GPUs largest-first by N^2.
+#   bin/run_all_amd.sh <input dir with *_matrix.txt> <output root> [n_gpus=1] [c3d_batch options: -m 20 -k 11 -a 0.5 ...]
+# (per-matrix Perl driver with the reference's own command line: bin/chromosome3D_amd.pl)
 set -u
 IN=${1:?input directory}; OUT=${2:?output root}; NG=${3:-1}; shift; shift; shift || true
 HERE=$(cd "$(dirname "$0")" && pwd)
-mkdir -p "$OUT"
-g=0
-for gpu in $(seq 0 $((NG - 1))); do
-  (
-    i=0
-    for m in $(ls "$IN"/*_matrix.txt | sort -V); do
-      if [ $((i % NG)) -eq "$gpu" ]; then
-        id=$(basename "$m" _matrix.txt)
-        echo "Running job for ${id} on GPU ${gpu}.."
-        perl "$HERE/chromosome3D_amd.pl" -if "$m" -o "$OUT/$id" --device "$gpu" "$@" &> "$OUT/$id.log" || echo "FAILED: $id (see $OUT/$id.log)"
-      fi
-      i=$((i + 1))
-    done
-  ) &
-done
-wait
-echo "all jobs finished; models under $OUT/<chromosome>/<ID>_model1..5.pdb"
+exec "$HERE/../chromosome3d_amd/_lib/c3d_batch" "$IN" --out "$OUT" --devices "$NG" "$@"

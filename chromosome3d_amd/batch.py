@@ -1,0 +1,165 @@
+"""Chromosome-sharded batch (BASELINE.json configs[3]: every 500 kb chromosome x 20 replicas over the GPUs of a node).
+
+    python -m chromosome3d_amd.batch [--inputs tests/golden/all45] [--pattern _500kb] [--models 20] [--out DIR]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m chromosome3d_amd.batch ...
+
+One process per GPU (the reference's only concurrency is one process per chromosome, test.sh:4-12).  Chromosomes go
+to ranks by longest-processing-time-first on their restraint counts (sharding.lpt_assign); every rank solves its
+chromosomes through the C ABI with `models` replicas each (replica ids 0..models-1, Philox keyed by (seed, replica):
+the models of a chromosome do not depend on which rank solved it); one all_gather of the per-model records
+{chromosome, replica, E_noe, Spearman, anneal ms} (RCCL on GPUs; C3D_BENCH_BACKEND=gloo for a rehearsal with fewer
+GPUs than ranks) brings everything to rank 0, which ranks the models of every chromosome as chromosome3D.pl:796-802
+does.  With --out every rank also writes the reference's output files for its chromosomes (pipeline.assess_dgsa).
+
+The single-process, thread-per-GPU twin of this module is the native c3d_batch executable (csrc/c3d_batch_main.cpp).
+"""
+import argparse
+import glob
+import json
+import os
+import re
+import sys
+import time
+
+import numpy as np
+
+from . import pipeline, sharding
+from .solver import Solver, default_model, default_schedule
+
+
+def load_matrices(inputs, pattern):
+    """{chromosome id: IF matrix} from a directory of packed upper triangles (*_upper.npz, tests/golden/all45) or of
+    the reference's text matrices (*_matrix.txt), filtered by `pattern`, in chromosome order."""
+    mats = {}
+    for p in glob.glob(os.path.join(inputs, "*_upper.npz")):
+        cid = os.path.basename(p)[:-len("_upper.npz")]
+        if pattern in cid:
+            z = np.load(p)
+            n = int(z["n"])
+            m = np.zeros((n, n))
+            iu = np.triu_indices(n)
+            m[iu] = z["upper"]
+            m.T[iu] = z["upper"]
+            mats[cid] = m
+    for p in glob.glob(os.path.join(inputs, "*_matrix.txt")):
+        cid = os.path.basename(p)[:-len("_matrix.txt")]
+        if pattern in cid and cid not in mats:
+            mats[cid] = pipeline.parse_if_file(p)
+
+    def key(c):
+        m = re.match(r"chr(\d+)_(\w+)", c)
+        return (m.group(2), int(m.group(1))) if m else (c, 0)
+    return {c: mats[c] for c in sorted(mats, key=key)}
+
+
+def job_costs(mats):
+    """~ restraint count of every chromosome: pairs i < j with |i - j| >= 5."""
+    return [(m.shape[0] - 5) * (m.shape[0] - 4) // 2 for m in mats.values()]
+
+
+def solve_assigned(solver, mats, mine, models=20, seed=82364, min_steps=3000, gtol=1e-2, out=None):
+    """Solve the chromosomes with indices `mine`; returns records [len(mine) * models, 5]:
+    chromosome index, replica, E_noe, Spearman(IF, d), anneal ms."""
+    cids = list(mats)
+    recs = []
+    for k in mine:
+        cid, IF = cids[k], mats[cids[k]]
+        solver.set_model(default_model())
+        d10 = pipeline.IF2dist_new(solver, IF)
+        solver.set_schedule(default_schedule(min_steps), None, gtol, 250)
+        solver.init_replicas(models, seed, 0)
+        solver.run()
+        x, e = solver.coords(), solver.energies()
+        rho = pipeline.spearman_IF_models(IF, x)
+        r = np.zeros((models, 5))
+        r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4] = k, np.arange(models), e[:, 0], rho, solver.last_timing()[0]
+        recs.append(r)
+        if out:
+            d = os.path.join(out, cid)
+            os.makedirs(d, exist_ok=True)
+            pipeline.write_front_half(d10, d, f"{cid}_matrix")
+            pipeline.assess_dgsa(d, f"{cid}_matrix", x, e, pipeline.restraints_from_dist10(d10), quiet=True)
+    return np.concatenate(recs) if recs else np.zeros((0, 5))
+
+
+def gather(rec, dist, device):
+    """all_gather of record blocks of different length; identity without a process group."""
+    if dist is None:
+        return rec
+    import torch
+    world = dist.get_world_size()
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([rec.shape[0]], dtype=torch.int64, device=device))
+    mmax = max(1, int(max(c.item() for c in counts)))
+    buf = torch.zeros((mmax, rec.shape[1]), dtype=torch.float64, device=device)
+    buf[: rec.shape[0]] = torch.from_numpy(rec).to(device)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return np.concatenate([o[: int(c.item())].cpu().numpy() for o, c in zip(outs, counts)])
+
+
+def rank_per_chromosome(rec, n_chrom):
+    """Per chromosome: replica order by ascending int(E_noe), ties by replica id (chromosome3D.pl:796-802)."""
+    out = []
+    for k in range(n_chrom):
+        r = rec[rec[:, 0] == k]
+        out.append(r[np.lexsort((r[:, 1], r[:, 2].astype(np.int64)))])
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ap.add_argument("--inputs", default=os.path.join(root, "tests", "golden", "all45"))
+    ap.add_argument("--pattern", default="_500kb")
+    ap.add_argument("--models", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=82364)
+    ap.add_argument("--min-steps", type=int, default=3000)
+    ap.add_argument("--out", default=None, help="write the reference's output files per chromosome under this directory")
+    ap.add_argument("--json", action="store_true", help="one JSON line with the per-chromosome ranking instead of the table")
+    args = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist, device = None, None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("C3D_BENCH_BACKEND", "nccl")
+        local = local % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
+        device = "cuda" if backend == "nccl" else "cpu"
+    t0 = time.perf_counter()
+    mats = load_matrices(args.inputs, args.pattern)
+    if not mats:
+        sys.exit(f"no matrices matching {args.pattern!r} under {args.inputs}")
+    mine = sharding.lpt_assign(job_costs(mats), world)[rank]
+    s = Solver(local)
+    t1 = time.perf_counter()
+    rec = solve_assigned(s, mats, mine, args.models, args.seed, args.min_steps, out=args.out)
+    t_solve = time.perf_counter() - t1
+    s.close()
+    rec = gather(rec, dist, device)
+    if rank == 0:
+        per = rank_per_chromosome(rec, len(mats))
+        if args.json:
+            print(json.dumps({"world": world, "chromosomes": {cid: {"order": [int(v) for v in r[:, 1]], "e_noe_int": [int(v) for v in r[:, 2]],
+                                                                     "spearman_best": round(-float(r[0, 3]), 6)}
+                                                               for cid, r in zip(mats, per)}}), flush=True)
+        else:
+            print(f"{len(mats)} chromosomes x {args.models} replicas on {world} rank(s); rank 0 solved {len(mine)} of them in {t_solve:.2f} s")
+            for cid, r in zip(mats, per):
+                print(f"  {cid:12s} N={mats[cid].shape[0]:4d} models={len(r):2d} best: replica {int(r[0, 1]):2d} E_noe={r[0, 2]:12.1f} "
+                      f"Spearman(IF,1/d)={-r[0, 3]:.4f}  anneal {r[0, 4]:.1f} ms")
+            print(f"  total wall incl. load/score {time.perf_counter() - t0:.2f} s; anneal device time summed over chromosomes "
+                  f"{sum(float(r[0, 4]) for r in per):.1f} ms")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,233 @@
+// c3d_batch — every chromosome of a directory in ONE process, one host thread and one libc3d context per GPU.
+//
+// The reference's only concurrency is test.sh:4-12: one `chromosome3D.pl -if <matrix> -o <dir> &` per matrix, each a
+// Perl process that shells out to CNS.  Here the whole per-matrix flow of chromosome3D.pl:86-106 runs natively behind
+// the C ABI (include/c3d.h) for every matrix:
+//   calc_len_IF / IF2dist_new / dist2rr / carr2tbl (:87-89)   c3d_parse_if_file, c3d_set_if_matrix (K1), c3d_write_front_half
+//   build_models (:104)                                       c3d_init_replicas, c3d_run
+//   assess_dgsa (:106, :769-829)                              c3d_rank, c3d_assess, c3d_write_pdb, c3d_shape_pdb, top 5 renamed
+// Matrices go to GPUs by longest-processing-time-first on N^2 (the restraint count), largest first on every GPU.
+//
+//   c3d_batch <dir with *_matrix.txt | matrix files...> --out <root> [--devices <all>] [-m 20] [-k 11] [-a 0.5]
+//             [--seed 82364] [--min-steps 3000] [--gtol 1e-2] [--pattern _500kb_]
+// Output: <root>/<chromosome>/ with the files a reference run leaves (<ID>.dist, .rr, contact.tbl, model_info.log,
+// <ID>_model1..5.pdb, <ID>_<k>.pdb) and <root>/<chromosome>.log with the satisfaction table; one summary line per matrix.
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/c3d.h"
+
+namespace {
+
+struct Job {
+    std::string path, id, chrom;
+    double cost = 0;
+    int device = -1;
+    bool ok = false;
+    std::string summary;
+};
+struct Options {
+    std::string out;
+    double K = 11, alpha = 0.5, gtol = 1e-2;
+    int models = 20, min_steps = 3000;
+    unsigned long long seed = 82364ULL;
+};
+std::mutex g_print;
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+#define TRY(call)                                                                                  \
+    do {                                                                                           \
+        if ((call) != C3D_OK) { job.summary = std::string(#call) + ": " + c3d_last_error(); return false; } \
+    } while (0)
+
+bool solve_one(c3d_ctx* ctx, const Options& o, Job& job) {
+    const double t0 = now_s();
+    const std::string dir = o.out + "/" + job.chrom;
+    mkdir(dir.c_str(), 0755);
+    c3d_model model;
+    c3d_default_model(&model);
+    TRY(c3d_set_model(ctx, &model));
+    double* IF = nullptr;
+    int n = 0, R = 0;
+    TRY(c3d_parse_if_file(job.path.c_str(), &IF, &n));
+    std::vector<double> if_copy(IF, IF + (size_t)n * n);
+    c3d_free(IF);
+    TRY(c3d_set_if_matrix(ctx, if_copy.data(), n, o.alpha, o.K));
+    std::vector<int32_t> d10((size_t)n * n);
+    TRY(c3d_get_dist10(ctx, d10.data()));
+    const std::string tbl = dir + "/contact.tbl";
+    TRY(c3d_write_front_half(d10.data(), n, model.min_sep, (dir + "/" + job.id + ".dist").c_str(), (dir + "/" + job.id + ".rr").c_str(),
+                             tbl.c_str(), &R));
+    std::vector<c3d_stage> stages(c3d_default_schedule(nullptr, 0, o.min_steps));
+    c3d_default_schedule(stages.data(), (int)stages.size(), o.min_steps);
+    c3d_fire_params fire;
+    c3d_default_fire(&fire);
+    TRY(c3d_set_schedule(ctx, stages.data(), (int)stages.size(), &fire, (float)o.gtol, 250));
+    TRY(c3d_init_replicas(ctx, o.models, o.seed, 0));
+    TRY(c3d_run(ctx));
+    double ms = 0;
+    long steps = 0, launches = 0;
+    c3d_last_timing(ctx, &ms, &steps, &launches);
+    const int M = o.models;
+    std::vector<float> xyz((size_t)M * n * 3);
+    std::vector<double> en((size_t)M * 3), rho(M);
+    std::vector<int32_t> rank(M);
+    TRY(c3d_get_coords(ctx, xyz.data()));
+    TRY(c3d_get_energies(ctx, en.data()));
+    TRY(c3d_rank(ctx, rank.data()));
+    TRY(c3d_spearman_if_dist_batch(if_copy.data(), xyz.data(), n, M, 3, rho.data()));
+    // restraint rows for the satisfaction table (:447-485, :581-600)
+    int32_t *pi = nullptr, *pj = nullptr, *pt = nullptr;
+    int Rt = 0;
+    TRY(c3d_read_tbl(tbl.c_str(), &pi, &pj, &pt, &Rt));
+    std::vector<int32_t> ri(pi, pi + Rt), rj(pj, pj + Rt), rt(pt, pt + Rt);
+    c3d_free(pi); c3d_free(pj); c3d_free(pt);
+    FILE* lg = fopen((o.out + "/" + job.chrom + ".log").c_str(), "w");
+    if (!lg) { job.summary = "cannot write the log"; return false; }
+    fprintf(lg, "L          : %d\nRestraints : %d lines in tbl file\n\nNOE_SATISFIED(+-0.5A)  SUM_OF_DEVIATIONS>= 0.2  PDB\n", n, R);
+    std::vector<std::string> names(M);
+    remove((dir + "/model_info.log").c_str());
+    for (int k = M - 1; k >= 0; --k) {               // the reference lists (and shapes) from the highest energy down (:805, :813)
+        const int r = rank[k];
+        char name[96];
+        snprintf(name, sizeof name, "%s_%d.pdb", job.id.c_str(), r + 1);
+        names[r] = dir + "/" + name;
+        TRY(c3d_write_pdb(names[r].c_str(), xyz.data() + (size_t)r * n * 3, n, en[3 * r], en[3 * r + 1], en[3 * r + 2], name));
+        int sat = 0;
+        double dev = 0;
+        TRY(c3d_assess(xyz.data() + (size_t)r * n * 3, n, Rt, ri.data(), rj.data(), rt.data(), 0.5, &sat, &dev));
+        char cnt[48], sd[48];
+        snprintf(cnt, sizeof cnt, "%d/%d", sat, Rt);
+        snprintf(sd, sizeof sd, "%.2f", dev);
+        std::string base(name);
+        base.resize(base.size() - 4);
+        fprintf(lg, "%-9s             %-9s                %-25s\n", cnt, sd, base.c_str());
+    }
+    for (int k = M - 1; k >= 0; --k) TRY(c3d_shape_pdb(names[rank[k]].c_str(), names[rank[k]].c_str(), (dir + "/model_info.log").c_str()));
+    fprintf(lg, "\n");
+    for (int k = 0; k < M && k < 5; ++k) {            // :822-828
+        char dst[96];
+        snprintf(dst, sizeof dst, "%s_model%d.pdb", job.id.c_str(), k + 1);
+        fprintf(lg, "model%d.pdb <= %s\n", k + 1, names[rank[k]].c_str());
+        if (rename(names[rank[k]].c_str(), (dir + "/" + dst).c_str()) != 0) { fclose(lg); job.summary = "rename failed"; return false; }
+    }
+    fclose(lg);
+    char buf[320];
+    snprintf(buf, sizeof buf, "%-14s N=%4d R=%6d  %2d models  best: replica %2d  E_noe %12.1f  Spearman(IF,1/d) %.4f  anneal %6.1f ms (%ld steps)  "
+                              "end-to-end %.2f s  GPU %d",
+             job.chrom.c_str(), n, R, M, rank[0] + 1, en[3 * rank[0]], -rho[rank[0]], ms, steps, now_s() - t0, job.device);
+    job.summary = buf;
+    return true;
+}
+
+void collect(const std::string& arg, const std::string& pattern, std::vector<Job>& jobs) {
+    struct stat st;
+    if (stat(arg.c_str(), &st) != 0) { fprintf(stderr, "c3d_batch: %s not found\n", arg.c_str()); exit(2); }
+    std::vector<std::string> files;
+    if (S_ISDIR(st.st_mode)) {
+        DIR* d = opendir(arg.c_str());
+        while (dirent* e = d ? readdir(d) : nullptr) {
+            const std::string f = e->d_name;
+            if (f.size() > 11 && f.compare(f.size() - 11, 11, "_matrix.txt") == 0) files.push_back(arg + "/" + f);
+        }
+        if (d) closedir(d);
+    } else {
+        files.push_back(arg);
+    }
+    std::sort(files.begin(), files.end());
+    for (const std::string& f : files) {
+        if (!pattern.empty() && f.find(pattern) == std::string::npos) continue;
+        Job j;
+        j.path = f;
+        std::string base = f.substr(f.find_last_of('/') + 1);
+        j.id = base.size() > 4 && base.compare(base.size() - 4, 4, ".txt") == 0 ? base.substr(0, base.size() - 4) : base;
+        j.chrom = j.id.size() > 7 && j.id.compare(j.id.size() - 7, 7, "_matrix") == 0 ? j.id.substr(0, j.id.size() - 7) : j.id;
+        stat(f.c_str(), &st);
+        j.cost = (double)st.st_size;                 // text bytes ~ N^2 ~ restraints
+        jobs.push_back(j);
+    }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Options o;
+    std::vector<std::string> inputs;
+    std::string pattern;
+    int devices = -1;
+    for (int a = 1; a < argc; ++a) {
+        const std::string s = argv[a];
+        auto next = [&](const char* what) -> const char* {
+            if (a + 1 >= argc) { fprintf(stderr, "c3d_batch: %s needs a value\n", what); exit(2); }
+            return argv[++a];
+        };
+        if (s == "--out" || s == "-o") o.out = next("--out");
+        else if (s == "--devices") devices = atoi(next("--devices"));
+        else if (s == "-m") o.models = atoi(next("-m"));
+        else if (s == "-k") o.K = atof(next("-k"));
+        else if (s == "-a") o.alpha = atof(next("-a"));
+        else if (s == "--seed") o.seed = strtoull(next("--seed"), nullptr, 10);
+        else if (s == "--min-steps") o.min_steps = atoi(next("--min-steps"));
+        else if (s == "--gtol") o.gtol = atof(next("--gtol"));
+        else if (s == "--pattern") pattern = next("--pattern");
+        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text]\n"); return 0; }
+        else inputs.push_back(s);
+    }
+    if (o.out.empty() || inputs.empty() || o.models < 1) { fprintf(stderr, "c3d_batch: need input matrices and --out <root> (see --help)\n"); return 2; }
+    std::vector<Job> jobs;
+    for (const std::string& in : inputs) collect(in, pattern, jobs);
+    if (jobs.empty()) { fprintf(stderr, "c3d_batch: no *_matrix.txt found\n"); return 2; }
+    const int ndev = c3d_device_count();
+    if (ndev < 1) { fprintf(stderr, "c3d_batch: no HIP device visible: libc3d has no CPU fallback\n"); return 1; }
+    if (devices < 1 || devices > ndev) devices = ndev;
+    mkdir(o.out.c_str(), 0755);
+    // longest-processing-time-first: biggest job to the least loaded GPU
+    std::vector<size_t> order(jobs.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].cost > jobs[b].cost; });
+    std::vector<double> load(devices, 0.0);
+    std::vector<std::vector<size_t>> mine(devices);
+    for (size_t k : order) {
+        const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        jobs[k].device = g;
+        load[g] += jobs[k].cost;
+        mine[g].push_back(k);
+    }
+    const double t0 = now_s();
+    std::atomic<int> failed{0};
+    std::vector<std::thread> workers;
+    for (int g = 0; g < devices; ++g)
+        workers.emplace_back([&, g]() {
+            c3d_ctx* ctx = nullptr;
+            if (c3d_create(g, &ctx) != C3D_OK) {
+                std::lock_guard<std::mutex> lk(g_print);
+                fprintf(stderr, "c3d_batch: GPU %d: %s\n", g, c3d_last_error());
+                failed += (int)mine[g].size();
+                return;
+            }
+            for (size_t k : mine[g]) {
+                Job& job = jobs[k];
+                job.ok = solve_one(ctx, o, job);
+                std::lock_guard<std::mutex> lk(g_print);
+                if (job.ok) printf("%s\n", job.summary.c_str());
+                else { printf("FAILED: %s (%s)\n", job.chrom.c_str(), job.summary.c_str()); ++failed; }
+                fflush(stdout);
+            }
+            c3d_destroy(ctx);
+        });
+    for (std::thread& w : workers) w.join();
+    printf("c3d_batch: %zu matrices x %d models on %d GPU(s) in %.2f s, %d failed; models under %s/<chromosome>/<ID>_model1..5.pdb\n", jobs.size(),
+           o.models, devices, now_s() - t0, failed.load(), o.out.c_str());
+    return failed.load() ? 1 : 0;
+}

@@ -160,7 +160,7 @@ def build_models(solver, model_count=MODELCOUNT, seed=MD_SEED, first_replica=0, 
     return solver.coords(), solver.energies()
 
 
-def assess_dgsa(out_dir, ID, xyz, energies, rows, top=5):
+def assess_dgsa(out_dir, ID, xyz, energies, rows, top=5, quiet=False):
     """Rank by int(E_noe) ascending (:796-802), print the satisfaction table (:804-810), write every
     model as <ID>_<k>.pdb, shape it as :813-820 does (CA rows renumbered, CONECT, REMARKs to model_info.log)
     and rename the best `top` to <ID>_model<i>.pdb (:822-828)."""
@@ -171,18 +171,19 @@ def assess_dgsa(out_dir, ID, xyz, energies, rows, top=5):
     for r in range(M):
         names[r] = os.path.join(out_dir, f"{ID}_{r + 1}.pdb")
         write_pdb(names[r], xyz[r], *energies[r], title=os.path.basename(names[r]))
-    print(f"NOE_SATISFIED(+-{DISTRELAX}A)  SUM_OF_DEVIATIONS>= 0.2  PDB")
+    say = (lambda *a: None) if quiet else print
+    say(f"NOE_SATISFIED(+-{DISTRELAX}A)  SUM_OF_DEVIATIONS>= 0.2  PDB")
     for r in reversed(order):
         sat, dev = assess(xyz[r], rows)
         report.append((r, sat, dev))
-        print("%-9s             %-9s                %-25s" % (f"{sat}/{len(rows[0])}", "%.2f" % dev,
-                                                              os.path.basename(names[r])[:-4]))
+        say("%-9s             %-9s                %-25s" % (f"{sat}/{len(rows[0])}", "%.2f" % dev,
+                                                            os.path.basename(names[r])[:-4]))
     for r in reversed(order):
         shape_pdb(names[r], None, os.path.join(out_dir, "model_info.log"))
     for k, r in enumerate(order[:top]):
         dst = os.path.join(out_dir, f"{ID}_model{k + 1}.pdb")
         os.replace(names[r], dst)
-        print(f"model{k + 1}.pdb <= {os.path.basename(names[r])}")
+        say(f"model{k + 1}.pdb <= {os.path.basename(names[r])}")
     return order, report
 
 

@@ -47,7 +47,7 @@ def test_anneal_recovers_synthetic_structure(solver, big):
     solver.set_model(default_model())
     pipeline.IF2dist_new(solver, IF)
     solver.set_schedule(default_schedule(1500), None, 0.0, 250)
-    solver.init_replicas(2, 82364, 0)
+    solver.init_replicas(8, 82364, 0)            # BASELINE configs[4]: 8 replicas
     solver.run()
     ms, steps, launches = solver.last_timing()
     x = solver.coords()
@@ -58,11 +58,17 @@ def test_anneal_recovers_synthetic_structure(solver, big):
     j = rng.integers(0, n, 200000)
     keep = np.abs(i - j) >= 3
     dt = np.linalg.norm(truth[i[keep]] - truth[j[keep]], axis=1)
-    for r in range(2):
+    for r in range(8):
         dm = np.linalg.norm(x[r, i[keep]] - x[r, j[keep]], axis=1)
         assert spearmanr(dt, dm)[0] > 0.9
         assert spearmanr(IF[i[keep], j[keep]], dm)[0] < -0.85
-    print(f"N=2500 x 2 replicas: {steps} SA steps in {ms:.1f} ms = {1e3 * ms / launches:.1f} us/step")
+    # the replicas are independent draws (different random coils), not copies
+    assert len({round(float(v), 1) for v in e[:, 0]}) == 8
+    # replica composition does not change a replica: replicas 2..3 alone reproduce columns 2..3 of the batch of eight
+    solver.init_replicas(2, 82364, 2)
+    solver.run()
+    assert np.array_equal(solver.coords(), x[2:4])
+    print(f"N=2500 x 8 replicas: {steps} SA steps in {ms:.1f} ms = {1e3 * ms / launches:.1f} us/step")
 
 
 @pytest.mark.gpu

@@ -81,3 +81,31 @@ def test_all_45_bundled_matrices(solver):
     assert not bad, bad
     assert (a <= 0.01).sum() >= 36 and (a <= 0.02).sum() >= 43 and a.max() <= 0.03 and a.mean() <= 0.0075, \
         ((a <= 0.01).sum(), (a <= 0.02).sum(), a.max(), a.mean())
+
+
+def test_config4_same_models_whatever_the_rank_count(tmp_path):
+    """BASELINE configs[3]: every 500 kb chromosome x 20 replicas through the product entry (python -m
+    chromosome3d_amd.batch), once in one process and once as two ranks (gloo rendezvous, both ranks on this box's GPU):
+    the per-chromosome ranking and the truncated NOE energies are identical — what a chromosome yields does not depend
+    on the rank that solved it (two processes sharing one GPU also exercise the abandoned-launch fallback)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable, "-m", "chromosome3d_amd.batch", "--json"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), "-m", "chromosome3d_amd.batch", "--json"], cwd=root,
+                         env=dict(env, C3D_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["world"] == 1 and b["world"] == 2 and len(a["chromosomes"]) == 22
+    assert a["chromosomes"] == b["chromosomes"]
+    assert all(len(c["order"]) == 20 for c in a["chromosomes"].values())

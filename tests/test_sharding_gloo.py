@@ -70,3 +70,57 @@ def test_gather_and_rank_world2():
         assert ids == [0.0, 1.0, 2.0, 3.0, 4.0]           # every rank sees all replicas, ordered by id
         assert np.allclose(e, e_all) and err == 0.0
         assert order == expect                              # identical ranking on every rank
+
+
+def _batch_worker(rank, world, port, q):
+    """chromosome3d_amd.batch on 2 gloo ranks, the solver replaced by a deterministic stand-in (no GPU here): the
+    LPT split, the variable-length all_gather and the per-chromosome ranking are the code the GPU run uses."""
+    import torch.distributed as dist
+    from chromosome3d_amd import batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = [40, 25, 31, 12, 18]
+        costs = [(n - 5) * (n - 4) // 2 for n in sizes]
+        mine = sharding.lpt_assign(costs, world)[rank]
+        recs = []
+        for k in mine:
+            rng = np.random.default_rng(1000 + k)                     # what a chromosome yields does not depend on the rank
+            r = np.zeros((6, 5))
+            r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4] = k, np.arange(6), rng.uniform(1e4, 1.001e4, 6), -rng.uniform(0.7, 0.9, 6), 1.0
+            recs.append(r)
+        rec = np.concatenate(recs) if recs else np.zeros((0, 5))
+        allrec = batch.gather(rec, dist, "cpu")
+        per = batch.rank_per_chromosome(allrec, len(sizes))
+        q.put((rank, sorted(mine), [[int(v) for v in r[:, 1]] for r in per], [len(r) for r in per]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chromosome_sharded_batch_world2():
+    """Config 4's N > 1 path: every chromosome is solved by exactly one rank, all ranks hold the same per-chromosome
+    ranking after the gather, and it equals the single-process ranking."""
+    import torch.multiprocessing as mp
+    from chromosome3d_amd import batch
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert sorted(res[0][1] + res[1][1]) == [0, 1, 2, 3, 4]            # a partition of the chromosomes
+    assert res[0][2] == res[1][2] and res[0][3] == [6] * 5
+    expect = []
+    for k in range(5):
+        rng = np.random.default_rng(1000 + k)
+        e = rng.uniform(1e4, 1.001e4, 6)
+        expect.append(sorted(range(6), key=lambda r: (int(e[r]), r)))  # ascending int(E_noe), ties by replica id
+    assert res[0][2] == expect
+    # the restraint-count cost of the bundled 500 kb matrices is what BASELINE.md lists
+    m = batch.load_matrices(os.path.join(ROOT, "tests", "golden", "all45"), "_500kb")
+    assert len(m) == 22 and list(m)[0] == "chr1_500kb" and batch.job_costs(m)[0] == 450 * 451 // 2
