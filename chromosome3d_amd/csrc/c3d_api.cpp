@@ -975,6 +975,8 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     else if (!strcmp(key, "cluster_parts")) *value = c->cl_ok ? (double)c->cl_plan.parts : 0.0;
     else if (!strcmp(key, "cluster_rows_per_wave")) *value = c->cl_ok ? (double)c->cl_plan.rpw : 0.0;
     else if (!strcmp(key, "cluster_compute_waves")) *value = c->cl_ok ? (double)c->cl_plan.cw : 0.0;
+    else if (!strcmp(key, "cluster_helper_waves")) *value = c->cl_ok ? (double)c->cl_plan.helpers : 0.0;
+    else if (!strcmp(key, "cluster_wgs_per_cu")) *value = c->cl_ok ? (double)c->cl_plan.wgs_per_cu : 0.0;
     else if (!strcmp(key, "replica_groups")) *value = (double)active_groups(c);
     else return fail(C3D_ERR_INVALID, std::string("c3d_get_stat: unknown key ") + key);
     return C3D_OK;

@@ -35,7 +35,6 @@
 namespace c3d {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kClHelpers = 4;
 constexpr int kClMaxThreads = 1024;
 
 // Diagnostic build only (-DC3D_STAMPS, tools/stamps): cycles per phase of helper H0 of workgroup (replica 0, part 0),
@@ -58,8 +57,8 @@ template <int POT, int RPW, int NB, bool RS1>
 __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const AnnealIO* __restrict__ io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
     const StepRun* __restrict__ runs, const int run0, const int skip0, const int nsteps, const unsigned tag_base,
-    volatile unsigned* __restrict__ timeout, unsigned* __restrict__ claim, const int P, const int CW, const DevModel m,
-    const DevFire fp) {
+    volatile unsigned* __restrict__ timeout, unsigned* __restrict__ claim, const int P, const int CW, const int NH,
+    const DevModel m, const DevFire fp) {
     constexpr int NPAD = 256 * NB;
     constexpr int MAXT = NPAD / 8;
     constexpr int KUMAX = NB > 2 ? 3 : 2;         // gather loads per thread: P * 2 RW <= threads * KUMAX
@@ -74,7 +73,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     int* s_slot = reinterpret_cast<int*>(dump + 4);
     float4* mwbuf = reinterpret_cast<float4*>(dump + 8);   // [CW][RPW * NB][64] NOE weights of the current run
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nthreads = (CW + kClHelpers) * 64;
+    const int nthreads = (CW + NH) * 64;           // NH helper waves: H0 + (NH - 1) chain helpers
     const int RW = CW * RPW;                      // rows of one workgroup: a multiple of 8 (whole tiles), <= 64
 
     // ---- placement: (replica, part) from this XCD's slot counter ---------------------------------
@@ -197,7 +196,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             CSTAMP(2);                              // sums + scalars
         } else if (p.kind != 4) {
             // ---- chain terms: lane = (row, neighbour), 16 rows per helper and pass ------------------------
-            for (int cb = 16 * (wave - CW - 1); cb < RW; cb += 16 * (kClHelpers - 1)) {
+            for (int cb = 16 * (wave - CW - 1); cb < RW; cb += 16 * (NH - 1)) {
                 const int k = cb + (lane >> 2);
                 float cx, cy, cz;
                 chain_term(m, p, xs, ys, zs, wg_row0 + k, lane & 3, k < RW, cx, cy, cz);
@@ -315,8 +314,8 @@ hipError_t read_cluster_stamps(unsigned long long* out) { return hipMemcpyFromSy
 #endif
 
 // ---- host side ---------------------------------------------------------------------------------------
-// Geometry.  A workgroup = CW compute waves x RPW rows (RW = CW * RPW rows, a multiple of 8, at most 64) + 4 helpers;
-// a replica = P = ceil(n / RW) workgroups; the replicas of the fullest XCD must fit its CUs, one workgroup per CU.
+// Geometry.  A workgroup = CW compute waves x RPW rows (RW = CW * RPW rows, a multiple of 8, at most 64) + 2 or 4 helpers;
+// a replica = P = ceil(n / RW) workgroups; the replicas of the fullest XCD must fit its CUs, one or two workgroups per CU.
 // Among the geometries that fit, the cheapest by an instruction-count model of one step (VALU issue is the limiter):
 //   per SIMD: ceil(CW / 4) compute waves x (RPW rows x NB blocks x 4 columns x 15 + 60) wave-instructions,
 //   + H0's serial tail (~200) + the hand-off (~570 instruction-times = 0.8 us) unless P == 1.
@@ -325,32 +324,40 @@ bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan) {
     const int cus_per_xcd = num_cus / 8;
     const int per_xcd = (m.nrep_g + 7) / 8;
     const int nb = m.npad / 256;
-    static const int geoms[][2] = {{8, 1}, {8, 2}, {12, 2}, {8, 4}, {10, 4}, {12, 4}, {8, 3}, {4, 2}, {4, 4}, {6, 4}};   // {CW, RPW}
+    // {compute waves, rows per wave, helper waves, workgroups per CU}
+    static const int geoms[][4] = {{8, 1, 4, 1}, {8, 2, 4, 1}, {12, 2, 4, 1}, {8, 4, 4, 1}, {10, 4, 4, 1}, {12, 4, 4, 1}, {8, 3, 4, 1},
+                                   {4, 2, 4, 1}, {4, 4, 4, 1}, {6, 4, 4, 1}};
+    // (two 512-thread workgroups per CU — {6, 4, 2, 2} and the like, meant to overlap one replica's serial phase with
+    //  another's pair loop — measured slower at every size: twice the records per replica, twice the helper work per CU)
     double best = 1e30;
     bool found = false;
-    const char* force = getenv("C3D_CLUSTER_GEOM");   // diagnostic: "CWxRPW", e.g. 12x4
-    int fcw = 0, frpw = 0;
-    if (force && sscanf(force, "%dx%d", &fcw, &frpw) != 2) fcw = frpw = 0;
+    const char* force = getenv("C3D_CLUSTER_GEOM");   // diagnostic: "CWxRPWxHELPERS", e.g. 12x4x4
+    int fcw = 0, frpw = 0, fnh = 0;
+    if (force && sscanf(force, "%dx%dx%d", &fcw, &frpw, &fnh) != 3) fcw = frpw = fnh = 0;
     for (const auto& g : geoms) {
-        const int cw = g[0], rpw = g[1], rw = cw * rpw;
-        if (fcw && (cw != fcw || rpw != frpw)) continue;
+        const int cw = g[0], rpw = g[1], nh = g[2], wpc = g[3], rw = cw * rpw;
+        if (fcw && (cw != fcw || rpw != frpw || nh != fnh)) continue;
         if (rw % 8 || rw > 64) continue;
-        if (rpw * nb > 8) continue;               // targets + weights in registers: 2 * rpw * nb float4 per lane
+        if (rpw * nb > 8) continue;               // targets in registers: rpw * nb float4 per lane
         const int P = (m.n + rw - 1) / rw;
-        if (per_xcd * P > cus_per_xcd) continue;
-        const int threads = (cw + kClHelpers) * 64;
+        if (per_xcd * P > cus_per_xcd * wpc) continue;
+        const int threads = (cw + nh) * 64;
         const int kumax = nb > 2 ? 3 : 2;
         if (P * 2 * rw > threads * kumax) continue;
-        const int wps = (cw + 3) / 4;             // compute waves per SIMD; a lone wave issues at ~0.6 of the multi-wave rate
-        const double cost = (wps == 1 ? 1.6 : (wps == 2 ? 1.15 : 1.0)) * wps * (rpw * nb * 60.0 + 60.0) + 200.0 + (P > 1 ? 570.0 : 0.0);
+        // coordinates, sums, row buffers + the compute waves' NOE weights
+        size_t lds = sizeof(float) * (3 * m.npad + 4 * (m.npad / 8) + 6 * 64 + 16) + (size_t)cw * rpw * nb * 64 * 16;
+        if (wpc == 1) { if (lds < 84 * 1024) lds = 84 * 1024; }    // more than half of a CU's 160 KB: one workgroup per CU
+        else if (lds > 78 * 1024 || threads > 512) continue;        // two per CU must fit
+        const int wps = (cw * wpc + 3) / 4;       // compute waves per SIMD; a lone wave issues at ~0.6 of the multi-wave rate
+        const double valu = (wps == 1 ? 1.6 : (wps == 2 ? 1.15 : 1.0)) * wps * (rpw * nb * 60.0 + 60.0);
+        const double serial = 200.0 + (P > 1 ? 570.0 : 0.0);
+        // one workgroup per CU: the serial tail of a step follows its pair loop; two per CU: the tails hide behind the
+        // other workgroup's loop where there is one
+        const double cost = wpc == 1 ? valu + serial : (valu > serial ? valu + 0.35 * serial : 0.5 * valu + serial);
         if (cost < best) {
             best = cost; found = true;
-            plan->rpw = rpw; plan->cw = cw; plan->parts = P; plan->per_xcd = per_xcd; plan->grid = num_cus; plan->threads = threads;
-            plan->units = 2 * rw; plan->device = 0;
-            // coordinates, sums, row buffers + the compute waves' NOE weights; at least 84 KB (more than half of a CU's
-            // 160 KB): one workgroup per CU
-            plan->lds = sizeof(float) * (3 * m.npad + 4 * (m.npad / 8) + 6 * 64 + 16) + (size_t)cw * rpw * nb * 64 * 16;
-            if (plan->lds < 84 * 1024) plan->lds = 84 * 1024;
+            plan->rpw = rpw; plan->cw = cw; plan->helpers = nh; plan->wgs_per_cu = wpc; plan->parts = P; plan->per_xcd = per_xcd;
+            plan->grid = num_cus * wpc; plan->threads = threads; plan->units = 2 * rw; plan->device = 0; plan->lds = lds;
         }
     }
     return found;
@@ -370,7 +377,7 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
         attr_set[dev] = true;
     }
     hipLaunchKernelGGL((k_cluster<POT, RPW, NB, RS1>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
-                       run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, m, fp);
+                       run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, m, fp);
     return hipGetLastError();
 }
 template <int POT>

@@ -94,12 +94,13 @@ struct AnnealIO {   // state buffers of one multi-step launch, in device memory 
 AnnealIO anneal_io(const DevBuffers& b, int parity);
 // cluster kernel (c3d_cluster.hip): many SA steps of the replica group [m.rep_base, m.rep_base + m.nrep_g) in ONE launch;
 // reads parity `parity` (through io), writes parity^1 once at the end.  A replica runs on `parts` workgroups of `threads`
-// threads (`cw` compute waves x `rpw` rows + 4 helper waves) of ONE XCD, one workgroup per CU, grid = number of CUs.
+// threads (`cw` compute waves x `rpw` rows + `helpers` helper waves) of ONE XCD, `wgs_per_cu` workgroups per CU, grid =
+// wgs_per_cu x number of CUs.
 // `runs` is the run-length coded step list of the WHOLE program (uploaded once); the launch starts `skip0` steps into
 // run `run0` and makes `nsteps` steps.  `tag_base` (launch sequence number << 20) keeps the tags of different launches
 // apart, `claim` points at 8 zeroed slot counters that no other launch has used, *timeout = 0.
 struct ClusterPlan {
-    int rpw, cw, parts, per_xcd, grid, threads, units, device;
+    int rpw, cw, helpers, wgs_per_cu, parts, per_xcd, grid, threads, units, device;
     size_t lds;
 };
 bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan);

@@ -42,7 +42,7 @@ def main():
         same = np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(ea, eb)
         print(f"{cid:12s} n={IF.shape[0]:4d} nrep={nrep:3d}  per-step {1e3 * ta[0] / ta[1]:7.3f} us/step ({ta[2]} launches, path {pa:.0f})   "
               f"cluster {1e3 * tb[0] / tb[1]:7.3f} us/step ({tb[2]} launches, path {pb:.0f}, parts {s.stat('cluster_parts'):.0f} "
-              f"cw {s.stat('cluster_compute_waves'):.0f} rpw {s.stat('cluster_rows_per_wave'):.0f}, fallbacks {fb - fb0:.0f})   steps {ta[1]}/{tb[1]}  bit-identical {same}", flush=True)
+              f"cw {s.stat('cluster_compute_waves'):.0f}+{s.stat('cluster_helper_waves'):.0f} x{s.stat('cluster_wgs_per_cu'):.0f}/CU rpw {s.stat('cluster_rows_per_wave'):.0f}, fallbacks {fb - fb0:.0f})   steps {ta[1]}/{tb[1]}  bit-identical {same}", flush=True)
         if not same:
             d = np.abs(xa - xb)
             print("   max |dx| =", d.max(), " first differing replica", int(np.argmax(d.reshape(nrep, -1).max(1) > 0)))
