@@ -140,6 +140,7 @@ struct c3d_ctx {
     unsigned* h_tmo = nullptr;             // hipHostMalloc'ed, mapped
     unsigned* h_tmo_dev = nullptr;         // its device address
 
+    long k1_recomputed = 0, k1_patched = 0;   // K1: near-tie elements redone on the host in the reference's order / changed by it
     long graph_captures = 0, graph_launches = 0, step_launches = 0, resident_launches = 0, cluster_launches = 0;
     int last_path = 0;                     // 0 per-step, 1 k_anneal, 2 k_cluster (what the last run_ops used)
 
@@ -668,6 +669,8 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     const size_t nn = (size_t)n * n;
     DevTmp<double> dIF, dP, dpart;
     DevTmp<int32_t> ddist;
+    DevTmp<unsigned char> dflags;
+    DevTmp<unsigned> dnflag;
     const int npartial = 64;
     if (c->buf.tgt) { hipFree(c->buf.tgt); c->buf.tgt = nullptr; }
     c->have_targets = false;
@@ -675,14 +678,51 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     HIP_TRY(hipMalloc(&dP.p, sizeof(double) * nn));
     HIP_TRY(hipMalloc(&dpart.p, sizeof(double) * npartial));
     HIP_TRY(hipMalloc(&ddist.p, sizeof(int32_t) * nn));
+    HIP_TRY(hipMalloc(&dflags.p, nn));
+    HIP_TRY(hipMalloc(&dnflag.p, sizeof(unsigned)));
     HIP_TRY(hipMalloc(&c->buf.tgt, sizeof(float) * (size_t)n * c->npad));
     HIP_TRY(hipMemcpyAsync(dIF.p, IF, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(dnflag.p, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(dflags.p, 0, nn, c->stream));
     hipError_t e = c3d::launch_if_to_target(dIF.p, n, c->npad, alpha, K, c->model.min_sep, c->model.rep_sep, dP.p, dpart.p,
-                                            npartial, ddist.p, c->buf.tgt, c->stream);
+                                            npartial, ddist.p, c->buf.tgt, dflags.p, dnflag.p, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("K1 launch: ") + hipGetErrorString(e));
     c->h_dist10.resize(nn);
+    unsigned nflag = 0;
     HIP_TRY(hipMemcpyAsync(c->h_dist10.data(), ddist.p, sizeof(int32_t) * nn, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&nflag, dnflag.p, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->k1_recomputed = 0;
+    if (nflag) {
+        // Near-tie elements: redo them exactly as the reference does (:132-161) — libm pow, the running sum over all N*N
+        // elements in row-major order, P / mean, K / that, "%.1f" — and patch the device copy where the tenth changed.
+        std::vector<unsigned char> flags(nn);
+        HIP_TRY(hipMemcpyAsync(flags.data(), dflags.p, nn, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        double sum = 0.0;
+        for (size_t k = 0; k < nn; ++k) sum += pow(IF[k], alpha);
+        const double mean = sum / ((double)n * (double)n);
+        for (size_t k = 0; k < nn; ++k) {
+            if (!flags[k]) continue;
+            double v = pow(IF[k], alpha) / mean;
+            if (v == 0) continue;
+            v = K / v;
+            char b[64];
+            snprintf(b, sizeof b, "%.1f", v);
+            char* dot = strchr(b, '.');
+            long long t = atoll(b) * 10 + (dot ? dot[1] - '0' : 0);
+            if (t > 2000000000LL) t = 2000000000LL;
+            ++c->k1_recomputed;
+            if ((int32_t)t == c->h_dist10[k]) continue;
+            c->h_dist10[k] = (int32_t)t;
+            const int i = (int)(k / n), j = (int)(k % n);
+            const int sep = i > j ? i - j : j - i;
+            const float enc = (sep >= c->model.min_sep && t > 0) ? (float)((double)t / 10.0) : 0.0f;
+            HIP_TRY(hipMemcpyAsync(c->buf.tgt + (size_t)i * c->npad + j, &enc, sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            ++c->k1_patched;
+        }
+    }
     int R = 0;
     for (int i = 0; i < n; ++i)
         for (int j = i + 1; j < n; ++j)
@@ -971,6 +1011,8 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     else if (!strcmp(key, "resident_launches")) *value = (double)c->resident_launches;
     else if (!strcmp(key, "cluster_launches")) *value = (double)c->cluster_launches;
     else if (!strcmp(key, "resident_fallbacks")) *value = (double)c->resident_fallbacks;
+    else if (!strcmp(key, "k1_recomputed")) *value = (double)c->k1_recomputed;
+    else if (!strcmp(key, "k1_patched")) *value = (double)c->k1_patched;
     else if (!strcmp(key, "last_path")) *value = (double)c->last_path;
     else if (!strcmp(key, "cluster_parts")) *value = c->cl_ok ? (double)c->cl_plan.parts : 0.0;
     else if (!strcmp(key, "cluster_rows_per_wave")) *value = c->cl_ok ? (double)c->cl_plan.rpw : 0.0;

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     }
 
 #ifdef C3D_STAMPS
-    const bool stamper = lrep == 0 && part == 0 && is_h0 && lane == 0;
+    const bool stamper = __builtin_amdgcn_readfirstlane(lrep == 0 && part == 0 && is_h0);   // wave-uniform: the stamps live in SGPRs
     unsigned long long cacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clast = __builtin_readcyclecounter();
 #endif
     int s = 0;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             }
         }
 #ifdef C3D_STAMPS
-        if (last && stamper) for (int k = 0; k < 10; ++k) g_cstamps[k] = cacc[k];
+        if (last && stamper && lane == 0) for (int k = 0; k < 10; ++k) g_cstamps[k] = cacc[k];
 #endif
         if (last) return;
         if (solo) continue;

@@ -354,9 +354,13 @@ __device__ __forceinline__ double round_tenths(double v) {
     return r;
 }
 
+// Elements whose K * mean / P * 10 lies within 1e-10 (relative) of a half-integer are FLAGGED: the device's pow() and its
+// tree sum may differ from the reference's libm pow and row-major running sum (chromosome3D.pl:132-139) by a few ulp,
+// which only such an element can notice.  The host recomputes the flagged ones in the reference's order (c3d_api.cpp).
 __global__ __launch_bounds__(256) void k_if_quantise(const double* __restrict__ P, const double* __restrict__ partial,
                                                     int npartial, int n, int npad, double K, int min_sep, int rep_sep,
-                                                    int32_t* __restrict__ dist10, float* __restrict__ tgt) {
+                                                    int32_t* __restrict__ dist10, float* __restrict__ tgt,
+                                                    unsigned char* __restrict__ flags, unsigned* __restrict__ nflag) {
     __shared__ double mean_s;
     if (threadIdx.x == 0) {
         double s = 0;
@@ -377,7 +381,12 @@ __global__ __launch_bounds__(256) void k_if_quantise(const double* __restrict__ 
                 double r = round_tenths(v);
                 if (r > 2.0e9) r = 2.0e9;
                 t10 = (int32_t)r;
+                const double p10 = v * 10.0;
+                const bool near_tie = fabs(fabs(p10 - floor(p10)) - 0.5) <= 1e-10 * p10 && p10 < 1.9e10;
+                flags[(size_t)i * n + j] = near_tie;
+                if (near_tie) atomicAdd(nflag, 1u);
             }
+            if (t10 == -10) flags[(size_t)i * n + j] = 0;
             dist10[(size_t)i * n + j] = t10;
             const int sep = i > j ? i - j : j - i;
             const bool noe = sep >= min_sep && t10 > 0;
@@ -391,12 +400,12 @@ __global__ __launch_bounds__(256) void k_if_quantise(const double* __restrict__ 
 
 hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, double K, int min_sep, int rep_sep,
                                double* scratchP, double* partial, int npartial, int32_t* dist10, float* tgt,
-                               hipStream_t s) {
+                               unsigned char* flags, unsigned* nflag, hipStream_t s) {
     hipLaunchKernelGGL(k_if_pow_sum, dim3(npartial), dim3(256), 0, s, IF, (size_t)n * n, alpha, scratchP, partial);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_if_quantise, dim3(n), dim3(256), 0, s, scratchP, partial, npartial, n, npad, K, min_sep, rep_sep,
-                       dist10, tgt);
+                       dist10, tgt, flags, nflag);
     return hipGetLastError();
 }
 

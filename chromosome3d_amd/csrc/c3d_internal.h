@@ -111,7 +111,7 @@ hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPla
 // K1: IF (n*n fp64, device) -> dist10 (n*n int32, device) and encoded targets (n*npad, device)
 hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, double K, int min_sep, int rep_sep,
                                double* scratchP, double* partial, int npartial, int32_t* dist10, float* tgt,
-                               hipStream_t s);
+                               unsigned char* flags, unsigned* nflag, hipStream_t s);
 
 // A7 (c3d_embed.hip): bead-level metric-matrix distance geometry for every replica
 hipError_t launch_dg_embed(const float* tgt, int n, int npad, int nrep, float b0, float lower, uint64_t seed,

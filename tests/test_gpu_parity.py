@@ -48,6 +48,31 @@ def test_k1_option_sweep(solver, O, K, alpha):
     assert np.array_equal(pipeline.IF2dist_new(solver, IF, K, alpha), O.if_to_dist10(IF, alpha, K))
 
 
+@pytest.mark.parametrize("alpha", [1.0, 0.5, 0.3])
+def test_k1_rounding_ties_are_recomputed_in_reference_order(solver, O, alpha):
+    """Adversarial matrices: dozens of entries whose distance K * mean / IF^alpha sits on (or within an ulp or two of) a
+    "%.1f" rounding tie, where one ulp of the mean (device tree sum against the reference's row-major running sum,
+    chromosome3D.pl:132-139) or of pow() decides the printed tenth.  The device flags such entries and the host redoes
+    them in the reference's order: bit-exact against the oracle's sequential restatement, whatever the ulps do."""
+    from chromosome3d_amd import pipeline
+    rng = np.random.default_rng(11)
+    n, K = 48, 11.0
+    A = rng.uniform(1.0, 400.0, size=(n, n))
+    IF = A + A.T
+    np.fill_diagonal(IF, 10.0 * IF.max())
+    picks = [(i, j, k + 0.05 + 0.1 * ((i + j) % 7)) for k, (i, j) in enumerate(zip(range(0, n - 6), range(6, n)), start=3)]
+    for _ in range(12):                       # fixed point: the mean depends on the entries being placed
+        mean = float((IF ** alpha).sum() / (n * n))
+        for i, j, t in picks:
+            IF[i, j] = IF[j, i] = (K * mean / t) ** (1.0 / alpha)
+    d = pipeline.IF2dist_new(solver, IF, K, alpha)
+    assert solver.stat("k1_recomputed") >= len(picks)         # both (i, j) and (j, i) of every pick, give or take an ulp
+    assert np.array_equal(d, O.if_to_dist10(IF, alpha, K))
+    # the targets the solver uses follow the patched tenths
+    solver.set_model(__import__("chromosome3d_amd").default_model())
+    assert solver.num_restraints == int((np.triu(d, 5) > 0).sum())
+
+
 def test_k1_synthetic_edge_cases(solver, O):
     from chromosome3d_amd import pipeline
     rng = np.random.default_rng(7)

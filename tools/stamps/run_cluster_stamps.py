@@ -10,7 +10,7 @@ import numpy as np
 s = Solver(0)
 L = lib.load()
 L.c3d_debug_cluster_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
-names = ["lds-write", "barrier1", "sums+scalars", "pair loop", "row update", "barrier2", "publish", "gather wait", "-", "sweeps"]
+names = ["lds-write+loop", "B1 wait", "H0 sums+scalars", "B2 wait (compute waves)", "H0 row update", "-", "H0 publish", "B3 + gather wait", "-", "sweeps"]
 cases = [a.split(":") for a in sys.argv[1:]] or [("chr21_1mb", "20"), ("chr4_1mb", "20"), ("chr1_500kb", "3"), ("chr1_500kb", "20")]
 for cid, nrep in cases:
     nrep = int(nrep)
