@@ -100,6 +100,7 @@ struct c3d_ctx {
     int rpw = 2;
     int stage_dma = 1;
     int graph_chunk = 256;
+    int start_mode = 0;                    // initial structure: 0 random coil, 1 extended strand (reference :2413-2416)
     int resident = -1;                     // multi-step cluster kernel (c3d_cluster.hip): 1 forced, 0 off, -1 where it applies
     int resident_min_ops = 4;              // shorter ranges go step by step
 
@@ -644,6 +645,11 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         return C3D_OK;
     }
     if (!strcmp(key, "resident")) { c->resident = value < 0 ? -1 : (value != 0); c->resident_skip = 0; return C3D_OK; }
+    if (!strcmp(key, "start")) {           // A5: 0 = Philox random coil, 1 = extended strand as extn.inp lays it out (:2413-2416)
+        if (value != 0 && value != 1) return fail(C3D_ERR_INVALID, "start must be 0 (random coil) or 1 (extended strand)");
+        c->start_mode = (int)value;
+        return C3D_OK;
+    }
     if (!strcmp(key, "cluster")) { c->cluster = value < 0 ? -1 : (value != 0); return C3D_OK; }
     if (!strcmp(key, "resident_inject_timeout")) { c->inject_timeout = value != 0; return C3D_OK; }   // test hook
     if (!strcmp(key, "resident_min_ops")) { c->resident_min_ops = value < 1 ? 1 : (int)value; return C3D_OK; }
@@ -812,6 +818,17 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
         std::vector<double> xd((size_t)3 * n);
         double px = 0, py = 0, pz = 0;
         for (int i = 0; i < n; ++i) {
+            if (c->start_mode == 1) {
+                // extended strand: the reference's template runs along x with small random y, z (`do (x=x/5.)`,
+                // `do (y=random(0.5))`, `do (z=random(0.5))`, :2413-2416) and is regularised to chain geometry; for
+                // beads: b0 apart along x, y and z uniform in [0, 0.5), keyed by (seed, replica, bead)
+                const uint32_t ctr[4] = {(uint32_t)i, 2u, 0u, 0u};
+                const uint32_t key[2] = {(uint32_t)(seed & 0xFFFFFFFFu) ^ (rid * 0x9E3779B9u), (uint32_t)(seed >> 32) + rid};
+                uint32_t u[4];
+                philox4x32(ctr, key, u);
+                xd[3 * i] = (double)c->model.b0 * i; xd[3 * i + 1] = 0.5 * u01(u[0]); xd[3 * i + 2] = 0.5 * u01(u[1]);
+                continue;
+            }
             if (i > 0) {
                 double g[4];
                 normals4(seed, rid, (uint32_t)i, 0u, g);
@@ -1011,6 +1028,15 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     else if (!strcmp(key, "resident_launches")) *value = (double)c->resident_launches;
     else if (!strcmp(key, "cluster_launches")) *value = (double)c->cluster_launches;
     else if (!strcmp(key, "resident_fallbacks")) *value = (double)c->resident_fallbacks;
+    else if (!strcmp(key, "rms_force")) {
+        // max over the replicas of the RMS force component at the last minimiser evaluation (what c3d_run compares with
+        // gtol); meaningful after a FIRE step only
+        double rms = 0;
+        if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_get_stat: rms_force needs replicas");
+        const int rc = max_rms_force(const_cast<c3d_ctx*>(c), &rms);
+        if (rc) return rc;
+        *value = rms;
+    }
     else if (!strcmp(key, "k1_recomputed")) *value = (double)c->k1_recomputed;
     else if (!strcmp(key, "k1_patched")) *value = (double)c->k1_patched;
     else if (!strcmp(key, "last_path")) *value = (double)c->last_path;

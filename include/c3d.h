@@ -144,7 +144,9 @@ int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* lau
  * "cluster_launches", "resident_fallbacks" (multi-step launches abandoned for the per-step path), "last_path"
  * (0 per-step, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "cluster_compute_waves", "replica_groups",
  * "k1_recomputed" (elements of the last c3d_set_if_matrix that sat within 1e-10 of a "%.1f" rounding tie and were redone
- * on the host in the reference's operation order), "k1_patched" (how many of those changed, since c3d_create). */
+ * on the host in the reference's operation order), "k1_patched" (how many of those changed, since c3d_create),
+ * "rms_force" (largest RMS force component over the replicas at the last minimiser step: the quantity c3d_run holds
+ * against gtol, the stand-in for L-BFGS's convergence test of chromosome3D.pl:1800-1803). */
 int c3d_get_stat(const c3d_ctx* ctx, const char* key, double* value);
 /* Name of the step kernel the last c3d_run / c3d_run_steps ran on, as a profiler prints it (thread-local string). */
 const char* c3d_step_kernel_name(const c3d_ctx* ctx);

@@ -109,3 +109,20 @@ def test_config4_same_models_whatever_the_rank_count(tmp_path):
     assert a["world"] == 1 and b["world"] == 2 and len(a["chromosomes"]) == 22
     assert a["chromosomes"] == b["chromosomes"]
     assert all(len(c["order"]) == 20 for c in a["chromosomes"].values())
+
+
+def test_final_minimisation_converges_at_the_headline_size(solver):
+    """The FIRE stand-in for the reference's <= 150 000-evaluation L-BFGS stage (deck :1790-1803) reaches the gradient
+    exit (max RMS force component < 1e-2 kcal/mol/A over all 20 replicas) well inside its 3000-step budget at N = 455
+    (profiles/r02_fire_convergence.txt: Spearman is converged to 5 decimals after ~300 steps, the force after ~2000)."""
+    from chromosome3d_amd import default_fire, default_model, default_schedule, pipeline
+    IF = _load("chr1_500kb")
+    solver.set_model(default_model())
+    pipeline.IF2dist_new(solver, IF)
+    solver.set_schedule(default_schedule(3000), default_fire(), 1e-2, 250)
+    solver.init_replicas(20, 82364, 0)
+    solver.run()
+    L = solver.schedule_length
+    ms, steps, launches = solver.last_timing()
+    assert 2172 + 500 <= steps <= L - 250, (steps, L)         # left through the gradient exit, not by running out of steps
+    assert solver.stat("rms_force") < 1e-2

@@ -203,6 +203,34 @@ def _setup(solver, cid, stages, nrep=2, seed=82364, **model_kw):
     return IF, d10, m, fire
 
 
+def test_extended_strand_start(solver):
+    """A5: the reference starts every model from an extended strand (x = id/5, y, z = random(0.5), chromosome3D.pl:2413-2416,
+    regularised to chain geometry).  Option start=1: beads b0 apart along x, y/z uniform in [0, 0.5), different per replica;
+    annealed from there the models land where the random-coil starts land (2000 K forgets the start)."""
+    from chromosome3d_amd import default_model, default_schedule, pipeline
+    IF = load_if("chr20_1mb")
+    n = IF.shape[0]
+    solver.set_model(default_model())
+    pipeline.IF2dist_new(solver, IF)
+    solver.set_schedule(default_schedule(1500), None, 0.0, 250)
+    out = {}
+    for mode in (1, 0):
+        solver.set_option("start", mode)
+        solver.init_replicas(8, 82364, 0)
+        x0 = solver.coords()
+        if mode == 1:
+            assert np.allclose(np.diff(x0[:, :, 0], axis=1), 3.8, atol=1e-4)
+            yz = x0[:, :, 1:] - x0[:, :, 1:].mean(axis=1, keepdims=True)
+            assert (np.abs(yz) <= 0.5).all() and np.ptp(x0[:, :, 1], axis=1).min() > 0.3
+            assert not np.allclose(x0[0, :, 1], x0[1, :, 1])                     # replicas differ
+            assert np.abs(x0.mean(axis=1)).max() < 1e-3                         # centred
+        solver.run()
+        out[mode] = -pipeline.spearman_IF_models(IF, solver.coords())
+    solver.set_option("start", 0)
+    assert abs(out[1].mean() - out[0].mean()) < 0.01 and abs(out[1].max() - out[0].max()) < 0.015
+    assert abs(out[1].mean() - -REF_SPEARMAN["chr20_1mb"]) < 0.02
+
+
 def test_initial_state_matches_oracle_rng(solver, O):
     IF, d10, m, fire = _setup(solver, "chr21_1mb", [(0, 1, 0.003, 1.0, 1.0, 0.9, 2000.0)], nrep=3)
     om = oracle_model_from(m, IF.shape[0])
