@@ -153,23 +153,23 @@ struct c3d_ctx {
 
 namespace {
 
+// hipFree of a context's buffer; a failure (only possible after a device fault) is kept in the error string, the
+// pointer is dropped either way
+template <class T>
+void dev_free(T*& p) {
+    if (!p) return;
+    const hipError_t e = hipFree(p);
+    if (e != hipSuccess) (void)fail(C3D_ERR_HIP, std::string("hipFree: ") + hipGetErrorString(e));
+    p = nullptr;
+}
+
 void free_replica_buffers(c3d_ctx* c) {
     for (int k = 0; k < 2; ++k) {
-        if (c->buf.X[k]) hipFree(c->buf.X[k]);
-        if (c->buf.V[k]) hipFree(c->buf.V[k]);
-        if (c->buf.P[k]) hipFree(c->buf.P[k]);
-        if (c->buf.S[k]) hipFree(c->buf.S[k]);
-        c->buf.X[k] = c->buf.V[k] = c->buf.P[k] = nullptr;
-        c->buf.S[k] = nullptr;
+        dev_free(c->buf.X[k]); dev_free(c->buf.V[k]); dev_free(c->buf.P[k]); dev_free(c->buf.S[k]);
     }
-    if (c->d_io) (void)hipFree(c->d_io);
-    if (c->d_crec) (void)hipFree(c->d_crec);
-    c->d_io = nullptr;
-    c->d_crec = nullptr; c->crec_bytes = 0; c->cl_ok = false;
-    if (c->buf.Vinit) hipFree(c->buf.Vinit);
-    if (c->buf.E) hipFree(c->buf.E);
-    if (c->d_feval) hipFree(c->d_feval);
-    c->buf.Vinit = nullptr; c->buf.E = nullptr; c->d_feval = nullptr;
+    dev_free(c->d_io); dev_free(c->d_crec);
+    c->crec_bytes = 0; c->cl_ok = false;
+    dev_free(c->buf.Vinit); dev_free(c->buf.E); dev_free(c->d_feval);
     c->have_replicas = false;
 }
 void drop_graphs(c3d_ctx* c) {
@@ -258,7 +258,7 @@ void build_program(c3d_ctx* c) {
 }
 
 int upload_targets(c3d_ctx* c, const std::vector<float>& enc) {
-    if (c->buf.tgt) { hipFree(c->buf.tgt); c->buf.tgt = nullptr; }
+    dev_free(c->buf.tgt);
     HIP_TRY(hipMalloc(&c->buf.tgt, sizeof(float) * enc.size()));
     HIP_TRY(hipMemcpyAsync(c->buf.tgt, enc.data(), sizeof(float) * enc.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -590,9 +590,8 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
     for (int g = 0; g < c3d_ctx::kMaxGroups; ++g) if (c->gstream[g]) hipStreamSynchronize(c->gstream[g]);
     drop_graphs(c);
     free_replica_buffers(c);
-    if (c->buf.tgt) hipFree(c->buf.tgt);
-    if (c->d_prog) (void)hipFree(c->d_prog);
-    if (c->d_claim) (void)hipFree(c->d_claim);
+    dev_free(c->buf.tgt);
+    dev_free(c->d_prog); dev_free(c->d_claim);
     if (c->h_tmo) (void)hipHostFree(c->h_tmo);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -678,7 +677,7 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     DevTmp<unsigned char> dflags;
     DevTmp<unsigned> dnflag;
     const int npartial = 64;
-    if (c->buf.tgt) { hipFree(c->buf.tgt); c->buf.tgt = nullptr; }
+    dev_free(c->buf.tgt);
     c->have_targets = false;
     HIP_TRY(hipMalloc(&dIF.p, sizeof(double) * nn));
     HIP_TRY(hipMalloc(&dP.p, sizeof(double) * nn));

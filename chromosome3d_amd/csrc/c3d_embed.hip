@@ -3,8 +3,8 @@
 // triangle smoothing ("shortest-path-algorithm auto"), random trial distances, embedding from the
 // leading eigenvectors of the metric matrix; one embed per model.  Restated for beads:
 //   k_dg_bounds          U = L = b0 for (i,i+1); U = L = t for restrained pairs; [lower, inf) otherwise
-//   k_dg_floyd_u / _l    all-pairs shortest paths on U, inverse triangle inequality on L (one launch per k;
-//                        row k and column k are fixed points of step k, so the update is safe in place)
+//   k_fw_u_* / k_fw_l_*  all-pairs shortest paths on U, inverse triangle inequality on L: blocked Floyd-Warshall,
+//                        32 x 32 tiles in LDS, three launches per 32 values of k
 //   k_dg_trial           per replica: d_ij = L + u (U - L), u ~ Philox4x32-10 counter (i, j, 2); stores d^2
 //   k_dg_eig             per replica, one workgroup: orthogonal iteration for the 3 leading eigenpairs of
 //                        B = -1/2 J D2 J (never formed: B v = -1/2 J (D2 (J v))), x = sqrt(lambda) v, centred
@@ -47,24 +47,140 @@ __global__ __launch_bounds__(256) void k_dg_bounds(const float* __restrict__ tgt
         L[(size_t)i * n + j] = l;
     }
 }
-__global__ __launch_bounds__(256) void k_dg_floyd_u(float* __restrict__ U, int n, int k) {
-    const int i = blockIdx.x;
-    const float uik = U[(size_t)i * n + k];
-    for (int j = threadIdx.x; j < n; j += 256) {
-        const float v = uik + U[(size_t)k * n + j];
-        if (v < U[(size_t)i * n + j]) U[(size_t)i * n + j] = v;
+// ---- bound smoothing: blocked Floyd-Warshall, 32 x 32 tiles in LDS, three phases per diagonal block ----------------
+// Upper bounds: all-pairs shortest paths, U_ij = min(U_ij, U_ik + U_kj).  Lower bounds (U final): the inverse triangle
+// inequality L_ij = max(L_ij, L_ik - U_kj, L_kj - U_ik).  Both have Floyd-Warshall's dependency pattern ((i,j) at step k
+// needs (i,k) and (k,j); row k and column k are fixed points of step k), so both run as the classic three-phase blocked
+// form: per diagonal block kb   1. the diagonal tile on itself   2. the tiles of block row / block column kb against it
+// 3. every other tile against its column-kb and row-kb tiles (no dependency inside the block step).
+// 3 launches per 32 values of k instead of 32 (N = 455: 45 + 45 launches instead of 910; N = 2500: 474 instead of 5000).
+// Every update is an implied bound, the closure is unique: same result as the one-k-per-launch form up to the rounding
+// of the path sums.  Indices >= n read as "no bound" (+inf above, -inf below) and are never written.
+constexpr int kFwB = 32;
+constexpr float kDgNegInf = -1.0e30f;
+
+template <bool LOWER>
+__device__ __forceinline__ void fw_load(const float* __restrict__ M, int n, int bi, int bj, float (*t)[kFwB + 1], int tid) {
+    for (int q = tid; q < kFwB * kFwB; q += 256) {
+        const int r = q / kFwB, c = q % kFwB, i = bi * kFwB + r, j = bj * kFwB + c;
+        t[r][c] = (i < n && j < n) ? M[(size_t)i * n + j] : (LOWER ? kDgNegInf : (i == j ? 0.0f : kDgInf));
     }
 }
-__global__ __launch_bounds__(256) void k_dg_floyd_l(float* __restrict__ L, const float* __restrict__ U, int n, int k) {
-    const int i = blockIdx.x;
-    const float lik = L[(size_t)i * n + k], uik = U[(size_t)i * n + k];
-    for (int j = threadIdx.x; j < n; j += 256) {
-        const float a = lik - U[(size_t)k * n + j];
-        const float b = L[(size_t)k * n + j] - uik;
-        const float v = fmaxf(L[(size_t)i * n + j], fmaxf(a, b));
+__device__ __forceinline__ void fw_store(float* __restrict__ M, int n, int bi, int bj, float (*t)[kFwB + 1], int tid) {
+    for (int q = tid; q < kFwB * kFwB; q += 256) {
+        const int r = q / kFwB, c = q % kFwB, i = bi * kFwB + r, j = bj * kFwB + c;
+        if (i < n && j < n) M[(size_t)i * n + j] = t[r][c];
+    }
+}
+
+// phase 1 (grid 1) and phase 2 (grid 2 (nb - 1): block-row tiles then block-column tiles) of the UPPER bounds
+__global__ __launch_bounds__(256) void k_fw_u_12(float* __restrict__ U, int n, int kb, int phase) {
+    __shared__ float D[kFwB][kFwB + 1], T[kFwB][kFwB + 1];
+    const int tid = threadIdx.x, nb = (n + kFwB - 1) / kFwB;
+    fw_load<false>(U, n, kb, kb, D, tid);
+    if (phase == 1) {
+        __syncthreads();
+        for (int k = 0; k < kFwB; ++k) {
+            for (int q = tid; q < kFwB * kFwB; q += 256) {
+                const int r = q / kFwB, c = q % kFwB;
+                D[r][c] = fminf(D[r][c], D[r][k] + D[k][c]);
+            }
+            __syncthreads();
+        }
+        fw_store(U, n, kb, kb, D, tid);
+        return;
+    }
+    int o = blockIdx.x % (nb - 1);
+    o += o >= kb;                                   // the other block index, skipping kb
+    const bool rowtile = blockIdx.x < nb - 1;       // tile (kb, o) else (o, kb)
+    const int bi = rowtile ? kb : o, bj = rowtile ? o : kb;
+    fw_load<false>(U, n, bi, bj, T, tid);
+    __syncthreads();
+    for (int k = 0; k < kFwB; ++k) {
+        for (int q = tid; q < kFwB * kFwB; q += 256) {
+            const int r = q / kFwB, c = q % kFwB;
+            T[r][c] = fminf(T[r][c], rowtile ? D[r][k] + T[k][c] : T[r][k] + D[k][c]);
+        }
+        __syncthreads();
+    }
+    fw_store(U, n, bi, bj, T, tid);
+}
+// phase 3 of the upper bounds: grid (nb - 1, nb - 1)
+__global__ __launch_bounds__(256) void k_fw_u_3(float* __restrict__ U, int n, int kb) {
+    __shared__ float A[kFwB][kFwB + 1], B[kFwB][kFwB + 1];
+    const int tid = threadIdx.x;
+    int bi = blockIdx.y, bj = blockIdx.x;
+    bi += bi >= kb; bj += bj >= kb;
+    fw_load<false>(U, n, bi, kb, A, tid);
+    fw_load<false>(U, n, kb, bj, B, tid);
+    __syncthreads();
+    for (int q = tid; q < kFwB * kFwB; q += 256) {
+        const int r = q / kFwB, c = q % kFwB, i = bi * kFwB + r, j = bj * kFwB + c;
+        if (i >= n || j >= n) continue;
+        float v = U[(size_t)i * n + j];
+#pragma unroll 8
+        for (int k = 0; k < kFwB; ++k) v = fminf(v, A[r][k] + B[k][c]);
+        U[(size_t)i * n + j] = v;
+    }
+}
+
+// the same three phases for the LOWER bounds (U is final): L_ij = max(L_ij, L_ik - U_kj, L_kj - U_ik)
+__global__ __launch_bounds__(256) void k_fw_l_12(float* __restrict__ L, const float* __restrict__ U, int n, int kb, int phase) {
+    __shared__ float LD[kFwB][kFwB + 1], UD[kFwB][kFwB + 1], LT[kFwB][kFwB + 1], UT[kFwB][kFwB + 1];
+    const int tid = threadIdx.x, nb = (n + kFwB - 1) / kFwB;
+    fw_load<true>(L, n, kb, kb, LD, tid);
+    fw_load<false>(U, n, kb, kb, UD, tid);
+    if (phase == 1) {
+        __syncthreads();
+        for (int k = 0; k < kFwB; ++k) {
+            for (int q = tid; q < kFwB * kFwB; q += 256) {
+                const int r = q / kFwB, c = q % kFwB;
+                LD[r][c] = fmaxf(LD[r][c], fmaxf(LD[r][k] - UD[k][c], LD[k][c] - UD[r][k]));
+            }
+            __syncthreads();
+        }
+        fw_store(L, n, kb, kb, LD, tid);
+        return;
+    }
+    int o = blockIdx.x % (nb - 1);
+    o += o >= kb;
+    const bool rowtile = blockIdx.x < nb - 1;
+    const int bi = rowtile ? kb : o, bj = rowtile ? o : kb;
+    fw_load<true>(L, n, bi, bj, LT, tid);
+    fw_load<false>(U, n, bi, bj, UT, tid);
+    __syncthreads();
+    for (int k = 0; k < kFwB; ++k) {
+        for (int q = tid; q < kFwB * kFwB; q += 256) {
+            const int r = q / kFwB, c = q % kFwB;
+            // row tile (i in block kb): L_ik, U_ik from the diagonal tile, L_kj, U_kj from this tile; column tile: the mirror
+            const float a = rowtile ? LD[r][k] - UT[k][c] : LT[r][k] - UD[k][c];
+            const float b = rowtile ? LT[k][c] - UD[r][k] : LD[k][c] - UT[r][k];
+            LT[r][c] = fmaxf(LT[r][c], fmaxf(a, b));
+        }
+        __syncthreads();
+    }
+    fw_store(L, n, bi, bj, LT, tid);
+}
+__global__ __launch_bounds__(256) void k_fw_l_3(float* __restrict__ L, const float* __restrict__ U, int n, int kb) {
+    __shared__ float LA[kFwB][kFwB + 1], UA[kFwB][kFwB + 1], LB[kFwB][kFwB + 1], UB[kFwB][kFwB + 1];
+    const int tid = threadIdx.x;
+    int bi = blockIdx.y, bj = blockIdx.x;
+    bi += bi >= kb; bj += bj >= kb;
+    fw_load<true>(L, n, bi, kb, LA, tid);
+    fw_load<false>(U, n, bi, kb, UA, tid);
+    fw_load<true>(L, n, kb, bj, LB, tid);
+    fw_load<false>(U, n, kb, bj, UB, tid);
+    __syncthreads();
+    for (int q = tid; q < kFwB * kFwB; q += 256) {
+        const int r = q / kFwB, c = q % kFwB, i = bi * kFwB + r, j = bj * kFwB + c;
+        if (i >= n || j >= n) continue;
+        float v = L[(size_t)i * n + j];
+#pragma unroll 8
+        for (int k = 0; k < kFwB; ++k) v = fmaxf(v, fmaxf(LA[r][k] - UB[k][c], LB[k][c] - UA[r][k]));
         L[(size_t)i * n + j] = v;
     }
 }
+
 __global__ __launch_bounds__(256) void k_dg_clamp(float* __restrict__ L, const float* __restrict__ U, size_t nn) {
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q < nn) L[q] = fminf(L[q], U[q]);
@@ -192,8 +308,21 @@ hipError_t launch_dg_embed(const float* tgt, int n, int npad, int nrep, float b0
                            uint32_t first_replica, int iters, const float* v0, float* U, float* L, float* D2, float* x0,
                            float* x1, hipStream_t s) {
     hipLaunchKernelGGL(k_dg_bounds, dim3(n), dim3(256), 0, s, tgt, n, npad, b0, lower, U, L);
-    for (int k = 0; k < n; ++k) hipLaunchKernelGGL(k_dg_floyd_u, dim3(n), dim3(256), 0, s, U, n, k);
-    for (int k = 0; k < n; ++k) hipLaunchKernelGGL(k_dg_floyd_l, dim3(n), dim3(256), 0, s, L, U, n, k);
+    const int nb = (n + kFwB - 1) / kFwB;
+    for (int kb = 0; kb < nb; ++kb) {
+        hipLaunchKernelGGL(k_fw_u_12, dim3(1), dim3(256), 0, s, U, n, kb, 1);
+        if (nb > 1) {
+            hipLaunchKernelGGL(k_fw_u_12, dim3(2 * (nb - 1)), dim3(256), 0, s, U, n, kb, 2);
+            hipLaunchKernelGGL(k_fw_u_3, dim3(nb - 1, nb - 1), dim3(256), 0, s, U, n, kb);
+        }
+    }
+    for (int kb = 0; kb < nb; ++kb) {
+        hipLaunchKernelGGL(k_fw_l_12, dim3(1), dim3(256), 0, s, L, U, n, kb, 1);
+        if (nb > 1) {
+            hipLaunchKernelGGL(k_fw_l_12, dim3(2 * (nb - 1)), dim3(256), 0, s, L, U, n, kb, 2);
+            hipLaunchKernelGGL(k_fw_l_3, dim3(nb - 1, nb - 1), dim3(256), 0, s, L, U, n, kb);
+        }
+    }
     const size_t nn = (size_t)n * n;
     hipLaunchKernelGGL(k_dg_clamp, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, L, U, nn);
     hipLaunchKernelGGL(k_dg_trial, dim3(n, nrep), dim3(256), 0, s, U, L, n, (uint32_t)(seed & 0xFFFFFFFFu),

@@ -368,7 +368,7 @@ def test_replica_groups_do_not_change_results(solver):
         assert np.array_equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1])
 
 
-@pytest.mark.parametrize("cid", ["chr21_1mb", "chr13_1mb"])
+@pytest.mark.parametrize("cid", ["chr21_1mb", "chr13_1mb", "chr19_500kb", "chr1_500kb"])
 def test_dg_embedding_matches_oracle(solver, O, cid):
     """A7 (deck :1471-1525, bead level): bounds -> smoothing -> trial distances -> top-3 eigenvectors.
     Eigenvector signs / rotations are gauge: compare the embedded pair distances."""
