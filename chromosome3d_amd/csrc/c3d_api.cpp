@@ -100,6 +100,9 @@ struct c3d_ctx {
     int rpw = 2;
     int stage_dma = 1;
     int graph_chunk = 256;
+    int sym = 0;                           // symmetric-tile step kernels (c3d_sym.hip): 1 on, 0 off (measured slower: DESIGN 7)
+    float* d_sym_scratch = nullptr;
+    int2* d_sym_tiles = nullptr;
     int start_mode = 0;                    // initial structure: 0 random coil, 1 extended strand (reference :2413-2416)
     int resident = -1;                     // multi-step cluster kernel (c3d_cluster.hip): 1 forced, 0 off, -1 where it applies
     int resident_min_ops = 4;              // shorter ranges go step by step
@@ -170,6 +173,7 @@ void free_replica_buffers(c3d_ctx* c) {
     dev_free(c->d_io); dev_free(c->d_crec);
     c->crec_bytes = 0; c->cl_ok = false;
     dev_free(c->buf.Vinit); dev_free(c->buf.E); dev_free(c->d_feval);
+    dev_free(c->d_sym_scratch); dev_free(c->d_sym_tiles);
     c->have_replicas = false;
 }
 void drop_graphs(c3d_ctx* c) {
@@ -300,11 +304,17 @@ void group_range(const c3d_ctx* c, int g, int& base, int& count) {
 }
 int active_groups(const c3d_ctx* c) { return std::min(c->ngroups, std::max(c->nrep, 1)); }
 
+bool use_sym(const c3d_ctx* c) {
+    if (!c->d_sym_scratch) return false;
+    return c->sym > 0;
+}
+
 // one SA-step launch for replica group g, reading parity `par`
 int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
     c3d::DevModel m = dev_model(c);
     group_range(c, g, m.rep_base, m.nrep_g);
-    hipError_t e = c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, general_tail(m), c->gstream[g]);
+    hipError_t e = use_sym(c) ? c3d::launch_step_sym(m, op.p, dev_fire(c), c->buf, par, c->d_sym_tiles, c->d_sym_scratch, c->gstream[g])
+                              : c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, general_tail(m), c->gstream[g]);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
     return C3D_OK;
 }
@@ -644,6 +654,12 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         return C3D_OK;
     }
     if (!strcmp(key, "resident")) { c->resident = value < 0 ? -1 : (value != 0); c->resident_skip = 0; return C3D_OK; }
+    if (!strcmp(key, "symmetric")) {       // takes effect at the next c3d_init_replicas with a new replica count / matrix
+        c->sym = value > 0;
+        free_replica_buffers(c);
+        drop_graphs(c);
+        return C3D_OK;
+    }
     if (!strcmp(key, "start")) {           // A5: 0 = Philox random coil, 1 = extended strand as extn.inp lays it out (:2413-2416)
         if (value != 0 && value != 1) return fail(C3D_ERR_INVALID, "start must be 0 (random coil) or 1 (extended strand)");
         c->start_mode = (int)value;
@@ -798,6 +814,17 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
             HIP_TRY(hipMalloc(&c->d_io, sizeof(io)));
             HIP_TRY(hipMemcpyAsync(c->d_io, io, sizeof(io), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            // symmetric-tile kernels (large N): tile list and the partial-force slabs
+            if (!general_tail(m) && c->sym > 0) {
+                int Q, G, od, dg;
+                c3d::sym_geometry(m, &Q, &G, &od, &dg);
+                std::vector<int2> tl((size_t)od + dg);
+                c3d::sym_tile_list(m, tl.data());
+                HIP_TRY(hipMalloc(&c->d_sym_tiles, sizeof(int2) * tl.size()));
+                HIP_TRY(hipMemcpyAsync(c->d_sym_tiles, tl.data(), sizeof(int2) * tl.size(), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                HIP_TRY(hipMalloc(&c->d_sym_scratch, sizeof(float) * c3d::sym_scratch_floats(m)));
+            }
             c->cl_ok = c3d::cluster_plan(m, c->num_cus, &c->cl_plan);
             if (c->cl_ok) {
                 c->cl_plan.device = c->device;
@@ -1057,6 +1084,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     const char* gen = general_tail(m) ? "true" : "false";
     const char* rs1 = (!general_tail(m) && m.rs == 1.0f) ? "true" : "false";
     if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %s>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, rs1);
+    else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);
     else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d, %s>", m.noe_pot, gen, m.rpw, rs1);
     return buf;
 }

@@ -108,6 +108,13 @@ size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl);
 hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout,
                           unsigned* claim, hipStream_t s);
+// symmetric-tile step for large N (c3d_sym.hip): every pair once.  tiles = sym_tile_list() uploaded, scratch =
+// sym_scratch_floats() floats of device memory (row-side and column-side partial forces of one step).
+void sym_geometry(const DevModel& m, int* Q, int* G, int* ntiles_offdiag, int* ntiles_diag);
+size_t sym_scratch_floats(const DevModel& m);
+void sym_tile_list(const DevModel& m, int2* out);
+hipError_t launch_step_sym(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int parity, const void* tiles,
+                           float* scratch, hipStream_t s);
 // K1: IF (n*n fp64, device) -> dist10 (n*n int32, device) and encoded targets (n*npad, device)
 hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, double K, int min_sep, int rep_sep,
                                double* scratchP, double* partial, int npartial, int32_t* dist10, float* tgt,

@@ -95,3 +95,40 @@ def test_cluster_kernel_every_column_block_count(solver, n, nrep):
     assert out[1][2] == 1 and out[0][2] > 60
     assert np.isfinite(out[0][0]).all()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1100, 1030])
+def test_symmetric_tile_step_matches_oracle_and_per_step_kernel(solver, n):
+    """Large-N step kernels (c3d_sym.hip: every pair once, row- and column-side partial forces summed in a fixed order):
+    short MD + FIRE trajectories against the fp64 oracle, and against the per-step kernel that walks full rows (the two
+    differ in the order of a row's sum, so within rounding, not bitwise).  n = 1030: a last row group of 6 rows and a
+    column block that is almost all padding."""
+    from chromosome3d_amd import default_fire, default_model, make_stages, pipeline
+    from oracle import oracle as O
+    from tests.util import oracle_fire_from, synthetic_if
+    IF, _ = synthetic_if(n, seed=5)
+    stages = [(2, 10, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 12, 0.003, 0.4, 0.003, 0.9, 2000.0), (1, 8, 0.005, 1.0, 0.05, 1.0, 1500.0),
+              (2, 10, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    m, fire = default_model(), default_fire()
+    out = {}
+    for sym in (1, 0):
+        solver.set_option("symmetric", sym)
+        solver.set_model(m)
+        d10 = pipeline.IF2dist_new(solver, IF)
+        solver.set_schedule(make_stages(stages), fire)
+        solver.init_replicas(2, 82364, 0)
+        x0 = solver.coords()
+        assert solver.run_steps(10 ** 6) == 40
+        out[sym] = (solver.coords(), solver.velocities(), solver.step_kernel_name)
+    solver.set_option("symmetric", 0)
+    assert "k_pairs_sym" in out[1][2] and "k_step" in out[0][2]
+    assert np.abs(out[1][0] - out[0][0]).max() < 5e-4 and np.abs(out[1][1] - out[0][1]).max() < 5e-3
+    om, of = oracle_model_from(m, n), oracle_fire_from(fire)
+    for r in range(2):
+        xo, vo, ev = O.run_schedule(om, d10, O.make_stages(stages), of, 82364, r, x0=x0[r].astype(np.float64))
+        xc = out[1][0][r].astype(np.float64)
+        xc -= xc.mean(0)
+        assert ev == 40
+        assert np.abs(xc - xo).max() < 2e-3, np.abs(xc - xo).max()
+        assert np.abs(out[1][1][r] - vo).max() < 2e-3 * max(1.0, np.abs(vo).max())
