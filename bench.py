@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=172)
     ap.add_argument("--reps", type=int, default=0, help="timed K-step regions (0 = 50 for K <= 100, else 5)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--dtype", choices=("f32", "f64"), default="f32",
+                    help="f64: the fp64 reference step (c3d_f64.hip, written for clarity) instead of the fp32 product kernels")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", type=int, default=REPLICAS, help="weak: per GPU; strong: in all")
@@ -152,6 +154,8 @@ def main():
     else:
         M, first, total_replicas = args.replicas, rank * args.replicas, args.replicas * world
     s = Solver(local_rank)
+    if args.dtype == "f64":
+        s.set_option("precision", 64)
     model, fire, stages = default_model(), default_fire(), default_schedule(MIN_STEPS)
     s.set_model(model)
     d10 = pipeline.IF2dist_new(s, IF)            # K1 on the GPU; targets stay resident in HBM
@@ -266,13 +270,14 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "bundled Hi-C matrix chr1_500kb (tests/golden/inputs, exact float64 upper triangle); random-coil starts, seed 82364",
             "config": {"workload": f"{WORKLOAD}: N={n} beads, R={R} restraints, {total_replicas} replicas in all "
                                    f"({'+'.join(str(c) for c in per_rank)} per GPU), default schedule "
                                    f"(200 FIRE + 1000 hot MD + 972 cool MD + {MIN_STEPS} FIRE = {L} SA steps)",
                        "replicas_per_gpu": per_rank, "parallelism": f"replica-sharded x{world}",
-                       "launch": {2: "one multi-step cluster launch per region", 0: "eager" if args.no_graph else "hipGraph"}.get(path, "?")},
+                       "launch": {2: "one multi-step cluster launch per region", 0: "eager" if args.no_graph else "hipGraph",
+                                  3: "fp64 reference: force + update launch per step"}.get(path, "?")},
             "reps": reps,
             "region_wall_ms": {"median": round(1e3 * wall, 4), "min": round(1e3 * min(walls), 4), "max": round(1e3 * max(walls), 4)},
             "device_ms_per_region": round(dev_ms, 4),

@@ -100,6 +100,10 @@ struct c3d_ctx {
     int rpw = 2;
     int stage_dma = 1;
     int graph_chunk = 256;
+    int precision = 32;                    // 64: the fp64 reference step (c3d_f64.hip) instead of the fp32 kernels
+    double *d64_X = nullptr, *d64_V = nullptr, *d64_F = nullptr, *d64_Vinit = nullptr, *d64_L = nullptr;
+    void* d64_fs = nullptr;
+    int32_t* d64_t10 = nullptr;
     int sym = 0;                           // symmetric-tile step kernels (c3d_sym.hip): 1 on, 0 off (measured slower: DESIGN 7)
     float* d_sym_scratch = nullptr;
     int2* d_sym_tiles = nullptr;
@@ -174,6 +178,7 @@ void free_replica_buffers(c3d_ctx* c) {
     c->crec_bytes = 0; c->cl_ok = false;
     dev_free(c->buf.Vinit); dev_free(c->buf.E); dev_free(c->d_feval);
     dev_free(c->d_sym_scratch); dev_free(c->d_sym_tiles);
+    dev_free(c->d64_X); dev_free(c->d64_V); dev_free(c->d64_F); dev_free(c->d64_Vinit); dev_free(c->d64_L); dev_free(c->d64_fs); dev_free(c->d64_t10);
     c->have_replicas = false;
 }
 void drop_graphs(c3d_ctx* c) {
@@ -378,10 +383,36 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     return C3D_OK;
 }
 
+// fp64 reference path: one force launch + one update launch per op on the context's stream; the fp32 buffers of the
+// current parity receive a copy of the state afterwards (read-back, energies, scoring, the minimiser's exit test)
+int run_ops64(c3d_ctx* c, size_t nops) {
+    const c3d::DevModel m = dev_model(c);
+    const c3d_model& h = c->model;
+    const double mh[14] = {h.s_noe, h.rswitch, h.asym, h.masym, h.mrswitch, h.k_bond, h.b0, h.k_ang, h.a0, h.r0_rep, h.k_rep, h.mass, h.fbeta,
+                           (double)h.min_sep};
+    const double fh[7] = {c->fire.dt_start, c->fire.dt_max, c->fire.f_inc, c->fire.f_dec, c->fire.alpha_start, c->fire.f_alpha, c->fire.max_step};
+    for (size_t k = 0; k < nops; ++k) {
+        const Op& op = c->program[c->pc + k];
+        const c3d_stage& st = c->stages[op.stage];
+        const double sh[6] = {(double)op.p.kind, st.dt, st.w_all, st.w_vdw, st.repel_s, st.t_bath};
+        hipError_t e = c3d::launch_step64(m, mh, sh, fh, c->fire.n_min, c->d64_t10, c->d64_X, c->d64_V, c->d64_F, c->d64_Vinit, c->d64_L,
+                                          c->d64_fs, c->stream);
+        if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 step launch: ") + hipGetErrorString(e));
+        if (op.counted) { ++c->steps_done; ++c->last_steps; }
+    }
+    hipError_t e = c3d::launch_export64(m, c->d64_X, c->d64_V, c->d64_L, c->buf.X[c->parity], c->buf.V[c->parity], c->buf.P[c->parity], c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 export: ") + hipGetErrorString(e));
+    c->last_launches += (long)nops;
+    c->pc += nops;
+    c->last_path = 3;
+    return C3D_OK;
+}
+
 // run program ops [pc, pc + nops): eager or via cached graphs; every replica group advances on its
 // own stream (fork from / join into stream 0 around the call)
 int run_ops(c3d_ctx* c, size_t nops) {
     if (nops == 0) return C3D_OK;
+    if (c->precision == 64) return run_ops64(c, nops);
     if (c->resident_skip > 0 && c->resident < 1) --c->resident_skip;     // cooling off after an abandoned launch
     else if (nops >= (size_t)c->resident_min_ops && nops < ((size_t)1 << 20)) {
         bool ran = false;
@@ -654,6 +685,13 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         return C3D_OK;
     }
     if (!strcmp(key, "resident")) { c->resident = value < 0 ? -1 : (value != 0); c->resident_skip = 0; return C3D_OK; }
+    if (!strcmp(key, "precision")) {       // 32 (the product kernels) or 64 (the fp64 reference step); call before c3d_init_replicas
+        if (value != 32 && value != 64) return fail(C3D_ERR_INVALID, "precision must be 32 or 64");
+        c->precision = (int)value;
+        free_replica_buffers(c);
+        drop_graphs(c);
+        return C3D_OK;
+    }
     if (!strcmp(key, "symmetric")) {       // takes effect at the next c3d_init_replicas with a new replica count / matrix
         c->sym = value > 0;
         free_replica_buffers(c);
@@ -838,6 +876,7 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
     // random coil (step b0) and Maxwell(0.5 K) velocities (deck :1646-1648), Philox keyed (seed, replica)
     const int n = c->n;
     std::vector<float> x((size_t)nrep * n * 3), v((size_t)nrep * n * 3);
+    std::vector<double> v64(c->precision == 64 ? (size_t)nrep * n * 3 : 0);
     const double sigma = sqrt((double)c3d::kBoltz * 0.5 * (double)c3d::kAccel / (double)c->model.mass);
     for (int r = 0; r < nrep; ++r) {
         const uint32_t rid = first_replica + (uint32_t)r;
@@ -876,6 +915,7 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
             v[((size_t)r * n + i) * 3 + 0] = (float)(sigma * g[0]);
             v[((size_t)r * n + i) * 3 + 1] = (float)(sigma * g[1]);
             v[((size_t)r * n + i) * 3 + 2] = (float)(sigma * g[2]);
+            if (!v64.empty()) for (int k = 0; k < 3; ++k) v64[((size_t)r * n + i) * 3 + k] = sigma * g[k];
         }
     }
     std::vector<float> soa;
@@ -894,6 +934,26 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
     }
     HIP_TRY(hipMemsetAsync(c->d_feval, 0, sizeof(float) * nf, c->stream));
     c->pc = 0; c->parity = 0; c->steps_done = 0;
+    if (c->precision == 64) {
+        if (c->h_dist10.empty()) return fail(C3D_ERR_INVALID, "precision 64 needs targets built from an IF matrix (integer tenths)");
+        const size_t n3 = (size_t)nrep * n * 3;
+        if (!c->d64_X) {
+            HIP_TRY(hipMalloc(&c->d64_X, sizeof(double) * n3));
+            HIP_TRY(hipMalloc(&c->d64_V, sizeof(double) * n3));
+            HIP_TRY(hipMalloc(&c->d64_F, sizeof(double) * n3));
+            HIP_TRY(hipMalloc(&c->d64_Vinit, sizeof(double) * n3));
+            HIP_TRY(hipMalloc(&c->d64_L, sizeof(double) * 4 * nrep));
+            HIP_TRY(hipMalloc(&c->d64_fs, c3d::fire_state64_bytes() * nrep));
+            HIP_TRY(hipMalloc(&c->d64_t10, sizeof(int32_t) * (size_t)n * n));
+            HIP_TRY(hipMemcpyAsync(c->d64_t10, c->h_dist10.data(), sizeof(int32_t) * (size_t)n * n, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(c->d64_Vinit, v64.data(), sizeof(double) * n3, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d64_L, 0, sizeof(double) * 4 * nrep, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d64_fs, 0, c3d::fire_state64_bytes() * nrep, c->stream));
+        hipError_t e = c3d::launch_import64(dev_model(c), c->buf.X[0], c->d64_X, c->d64_V, c->stream);
+        if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 import: ") + hipGetErrorString(e));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return C3D_OK;
 }
 
@@ -1085,6 +1145,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     const char* rs1 = (!general_tail(m) && m.rs == 1.0f) ? "true" : "false";
     if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %s>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, rs1);
     else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);
+    else if (c->precision == 64) snprintf(buf, sizeof(buf), "c3d::k64_force");
     else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d, %s>", m.noe_pot, gen, m.rpw, rs1);
     return buf;
 }

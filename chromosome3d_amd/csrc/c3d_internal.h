@@ -115,6 +115,15 @@ size_t sym_scratch_floats(const DevModel& m);
 void sym_tile_list(const DevModel& m, int2* out);
 hipError_t launch_step_sym(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int parity, const void* tiles,
                            float* scratch, hipStream_t s);
+// fp64 step (c3d_f64.hip, option "precision" = 64): the oracle's algorithm in the oracle's precision on the GPU.
+// model_host[14] = s_noe, rswitch, asym, masym, mrswitch, k_bond, b0, k_ang, a0, r0_rep, k_rep, mass, fbeta, min_sep;
+// step_host[6] = kind, dt, w_all, w_vdw, repel_s, t_bath; fire_host[7] = dt_start, dt_max, f_inc, f_dec, alpha_start, f_alpha, max_step.
+// X, V, F, Vinit: [nrep][n][3] doubles; L: [nrep][4]; fs: nrep * fire_state64_bytes(); t10: n*n tenths of an Angstrom.
+hipError_t launch_step64(const DevModel& d, const double* model_host, const double* step_host, const double* fire_host, int fire_n_min,
+                         const int32_t* t10, double* X, double* V, double* F, const double* Vinit, double* L, void* fs, hipStream_t s);
+hipError_t launch_import64(const DevModel& d, const float* Xf, double* X, double* V, hipStream_t s);
+hipError_t launch_export64(const DevModel& d, const double* X, const double* V, const double* L, float* Xf, float* Vf, float* Pf, hipStream_t s);
+size_t fire_state64_bytes();
 // K1: IF (n*n fp64, device) -> dist10 (n*n int32, device) and encoded targets (n*npad, device)
 hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, double K, int min_sep, int rep_sep,
                                double* scratchP, double* partial, int npartial, int32_t* dist10, float* tgt,

@@ -278,6 +278,53 @@ def test_fire_short_trajectory(solver, O, cid):
         assert np.abs(xc - xo).max() < 2e-3, np.abs(xc - xo).max()
 
 
+@pytest.mark.parametrize("cid,nsteps", [("chr21_1mb", (60, 250, 120, 150)), ("chr20_1mb", (40, 150, 60, 80))])
+def test_fp64_path_follows_the_oracle_over_long_trajectories(solver, O, cid, nsteps):
+    """Option precision = 64 (c3d_f64.hip): the oracle's algorithm in the oracle's precision on the GPU.  Hundreds of
+    chaotic MD steps at 2000 K and two minimisations stay within 1e-7 A of the CPU oracle (the fp32 kernels can only be
+    held to it for ~20 steps, test_md_short_trajectory): the algorithm the product runs IS the oracle's."""
+    a, b, c, d = nsteps
+    stages = [(2, a, 0.0, 1.0, 20.0, 0.5, 0.0), (0, b, 0.003, 0.4, 0.003, 0.9, 2000.0), (1, c, 0.005, 1.0, 0.05, 1.0, 1500.0),
+              (2, d, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    solver.set_option("precision", 64)
+    try:
+        IF, d10, m, fire = _setup(solver, cid, stages)
+        x0 = solver.coords()
+        assert solver.run_steps(10 ** 6) == a + b + c + d
+        assert solver.step_kernel_name == "c3d::k64_force"
+        x, v = solver.coords(), solver.velocities()
+        om, of = oracle_model_from(m, IF.shape[0]), oracle_fire_from(fire)
+        for r in range(2):
+            xo, vo, ev = O.run_schedule(om, d10, O.make_stages(stages), of, 82364, r, x0=x0[r].astype(np.float64))
+            xc = x[r].astype(np.float64)
+            xc -= xc.mean(0)
+            assert ev == a + b + c + d
+            assert np.abs(xc - xo).max() < 2e-5, np.abs(xc - xo).max()       # the read-back is fp32: 1e-5 A at |x| ~ 50
+            assert np.abs(v[r] - vo).max() < 2e-5 * max(1.0, np.abs(vo).max())
+    finally:
+        solver.set_option("precision", 32)
+
+
+def test_fp32_product_against_the_fp64_reference_statistics(solver):
+    """What fp32 costs: the full default schedule, 20 replicas of chr21_1mb, in both precisions.  Trajectories differ
+    (chaos), the ensembles do not: Spearman(IF, 1/d) mean and best within 0.003, median NOE energy within 1 %."""
+    from chromosome3d_amd import default_fire, default_model, default_schedule, pipeline
+    IF = load_if("chr21_1mb")
+    res = {}
+    for prec in (64, 32):
+        solver.set_option("precision", prec)
+        solver.set_model(default_model())
+        pipeline.IF2dist_new(solver, IF)
+        solver.set_schedule(default_schedule(3000), default_fire(), 0.0, 250)
+        solver.init_replicas(20, 82364, 0)
+        solver.run()
+        rho = -pipeline.spearman_IF_models(IF, solver.coords())
+        res[prec] = (rho.mean(), rho.max(), float(np.median(solver.energies()[:, 0])))
+    solver.set_option("precision", 32)
+    assert abs(res[64][0] - res[32][0]) < 0.003 and abs(res[64][1] - res[32][1]) < 0.003
+    assert abs(res[64][2] - res[32][2]) < 0.01 * res[64][2]
+
+
 def test_graph_replay_is_bitwise_eager(solver):
     from chromosome3d_amd import default_schedule
     stages = [(2, 40, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 60, 0.003, 0.2, 20.0, 0.5, 2000.0), (1, 24, 0.005, 1.0, 0.01, 1.0, 1900.0),
