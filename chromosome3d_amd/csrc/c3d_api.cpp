@@ -1243,10 +1243,6 @@ extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
 
 #ifdef C3D_STAMPS
 namespace c3d { hipError_t read_stamps(unsigned long long* out); hipError_t read_cluster_stamps(unsigned long long* out); }
-namespace c3d { hipError_t read_debug_forces(float* out); hipError_t read_debug_forces_step(float* out); }
-extern "C" int c3d_debug_forces(float* out, int which) {
-    return (which ? c3d::read_debug_forces(out) : c3d::read_debug_forces_step(out)) == hipSuccess ? C3D_OK : C3D_ERR_HIP;
-}
 extern "C" int c3d_debug_cluster_stamps(unsigned long long* out) {
     hipError_t e = c3d::read_cluster_stamps(out);
     return e == hipSuccess ? C3D_OK : C3D_ERR_HIP;

@@ -40,17 +40,14 @@ constexpr int kClMaxThreads = 1024;
 // Diagnostic build only (-DC3D_STAMPS, tools/stamps): cycles per phase of helper H0 of workgroup (replica 0, part 0),
 // summed over the steps of a launch, plus the number of gather sweeps.
 #ifdef C3D_STAMPS
-__device__ unsigned long long g_cstamps[16];
-#define CSTAMP(k)                                                                                       \
-    do {                                                                                                \
-        if (stamper) {                                                                                  \
-            const unsigned long long t_ = __builtin_readcyclecounter();                                 \
-            cacc[k] += t_ - clast;                                                                      \
-            clast = t_;                                                                                 \
-        }                                                                                               \
-    } while (0)
+// raw s_memrealtime stamps (100 MHz) of the last 64 steps of a launch: [step & 63][point], written by one lane of the
+// stamping wave (H0 of replica 0 part 0 for points 0..5, compute wave 0 of the same workgroup for points 6..7)
+__device__ unsigned long long g_cstamps[64][8];
+#define CSTAMP(k) do { if (stamper) g_cstamps[s & 63][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CSTAMP_C(k) do { if (cstamper) g_cstamps[s & 63][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CSTAMP(k) do { } while (0)
+#define CSTAMP_C(k) do { } while (0)
 #endif
 
 template <int POT, int RPW, int NB, bool RS1>
@@ -85,13 +82,15 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     if (lrep >= m.nrep_g) return;                 // this CU has nothing to do
     const int rep = m.rep_base + lrep;
     const bool solo = P == 1;
-    const bool is_compute = wave < CW, is_h0 = wave == CW;
-    // the helpers' instruction chains are the serial part of a step: they issue ahead of the compute waves of their SIMD
+    // waves 0 .. NH-1 are the helpers (the OLDEST waves of their SIMDs: instruction arbitration favours age, and the
+    // helpers' chains are the serial part of a step), waves NH .. NH+CW-1 compute
+    const bool is_compute = wave >= NH, is_h0 = wave == 0;
+    const int cwave = wave - NH;                  // compute wave index
     if (!is_compute) __builtin_amdgcn_s_setprio(3);
 
     const size_t roff = (size_t)rep * 3 * NPAD;
     const int wg_row0 = part * RW;
-    const int row0 = wg_row0 + wave * RPW;        // compute waves: first row of the wave
+    const int row0 = wg_row0 + cwave * RPW;       // compute waves: first row of the wave
     const int hrow = wg_row0 + lane;              // H0: the row of this lane
     const bool hfin = is_h0 && lane < RW && hrow < m.n;
 #define C3D_HROW_INDEX const size_t ix = roff + hrow, iy = ix + NPAD, iz = iy + NPAD   /* formed where used: H0 only */
@@ -142,8 +141,8 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     }
 
 #ifdef C3D_STAMPS
-    const bool stamper = __builtin_amdgcn_readfirstlane(lrep == 0 && part == 0 && is_h0);   // wave-uniform: the stamps live in SGPRs
-    unsigned long long cacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clast = __builtin_readcyclecounter();
+    const bool stamper = lrep == 0 && part == 0 && is_h0 && lane == 0;
+    const bool cstamper = lrep == 0 && part == 0 && cwave == 0 && lane == 0;
 #endif
     int s = 0;
     for (int run = run0;; ++run) {                  // left by the `return` of the last step
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
       const int count = runs[run].count;
       const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
       // NOE weight of every pair of this wave for this run (-2 w S or 0): wave-private LDS, no barrier needed
-      float4* const mw = mwbuf + (size_t)wave * (RPW * NB * 64);
+      float4* const mw = mwbuf + (size_t)(is_compute ? cwave : 0) * (RPW * NB * 64);
       if (is_compute) {
 #pragma unroll
           for (int r = 0; r < RPW; ++r)
@@ -159,10 +158,11 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
               for (int jb = 0; jb < NB; ++jb) mw[(r * NB + jb) * 64 + lane] = noe_weights(p, tv[r][jb]);
       }
       for (int it = run == run0 ? skip0 : 0; it < count; ++it, ++s) {
-        CSTAMP(0);                                  // LDS writes of the gather / loop bookkeeping
         __syncthreads();                            // B1: xs/ys/zs/ps of this step are in LDS
-        CSTAMP(1);                                  // barrier wait
+        CSTAMP(0);                                  // step start (H0 past B1)
+        CSTAMP_C(6);                                // compute wave 0 past B1
 
+        float hx0 = 0.0f, hy0 = 0.0f, hz0 = 0.0f;  // H0: position of this lane's row
         StepScalars sc;
         sc.lam = 1.0f; sc.cmx = sc.cmy = sc.cmz = 0.0f; sc.keep = 0.0f; sc.mix = 0.0f;
         if (is_compute) {
@@ -171,9 +171,10 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 float Fx, Fy, Fz;
                 tile_pair_sums_reg<POT, RPW, NB, true, RS1>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
                 if (lane < RPW) {
-                    const int k = wave * RPW + lane;
+                    const int k = cwave * RPW + lane;
                     fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz;
                 }
+                CSTAMP_C(7);                        // compute wave 0: pair loop + reduce done
             }
         } else if (is_h0) {
             // ---- replica sums of the previous step -> scalars of this one (only H0 needs them) -----------
@@ -193,10 +194,12 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 psum.w = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(psum.w)));
             }
             sc = step_scalars(m, p, fp, psum, st);
-            CSTAMP(2);                              // sums + scalars
+            // this row's position: read now, the barrier below is long
+            if (lane < RW && hrow < NPAD) { hx0 = xs[hrow]; hy0 = ys[hrow]; hz0 = zs[hrow]; }
+            CSTAMP(1);                              // H0: sums + scalars done
         } else if (p.kind != 4) {
             // ---- chain terms: lane = (row, neighbour), 16 rows per helper and pass ------------------------
-            for (int cb = 16 * (wave - CW - 1); cb < RW; cb += 16 * (NH - 1)) {
+            for (int cb = 16 * (wave - 1); cb < RW; cb += 16 * (NH - 1)) {
                 const int k = cb + (lane >> 2);
                 float cx, cy, cz;
                 chain_term(m, p, xs, ys, zs, wg_row0 + k, lane & 3, k < RW, cx, cy, cz);
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             }
         }
         __syncthreads();                            // B2: all LDS reads of this step are done; fbuf / cbuf complete
-        CSTAMP(3);                                  // wait for the compute waves
+        CSTAMP(2);                                  // H0 past B2 (all compute waves done)
         const bool last = s + 1 == nsteps;
         const unsigned tag = tag_base + (unsigned)s + 1u;
         const int base = (((s + 1) & 1) * m.nrep_g + lrep) * units;
@@ -217,23 +220,19 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             if (hfin) {
                 float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
                 if (p.kind != 4) { Fx = fbuf[lane] + cbuf[lane]; Fy = fbuf[64 + lane] + cbuf[64 + lane]; Fz = fbuf[128 + lane] + cbuf[128 + lane]; }
-#ifdef C3D_STAMPS
-                if (rep == 0 && p.kind != 4 && hrow < 1024)
-                    for (int c = 0; c < 3; ++c) { g_dbgF[1][c][hrow] = fbuf[64 * c + lane]; g_dbgF[1][3 + c][hrow] = cbuf[64 * c + lane]; }
-#endif
                 float vx0 = vcx, vy0 = vcy, vz0 = vcz;
                 if (p.kind == 3) { vx0 = vy0 = vz0 = 0.0f; }
                 else if (p.kind == 4) { C3D_HROW_INDEX; const float* vinit = io->vinit; vx0 = vinit[ix]; vy0 = vinit[iy]; vz0 = vinit[iz]; }
-                finish_row(m, p, fp, sc, st, Fx, Fy, Fz, xs[hrow], ys[hrow], zs[hrow], vx0, vy0, vz0, xn, yn, zn, vcx, vcy, vcz, q);
-            } else if (lane < RW && hrow < NPAD) {
-                xn = xs[hrow]; yn = ys[hrow]; zn = zs[hrow];    // padding row: republish as is
+                finish_row(m, p, fp, sc, st, Fx, Fy, Fz, hx0, hy0, hz0, vx0, vy0, vz0, xn, yn, zn, vcx, vcy, vcz, q);
+            } else {
+                xn = hx0; yn = hy0; zn = hz0;       // padding row: republish as is
             }
             // tile sums, the tree of tile_sum8 over eight consecutive lanes: lane 8 t ends with tile t's four sums
             float4 t = q;
             t.x += dpp_mov<0xB1>(t.x); t.y += dpp_mov<0xB1>(t.y); t.z += dpp_mov<0xB1>(t.z); t.w += dpp_mov<0xB1>(t.w);
             t.x += dpp_mov<0x4E>(t.x); t.y += dpp_mov<0x4E>(t.y); t.z += dpp_mov<0x4E>(t.z); t.w += dpp_mov<0x4E>(t.w);
             t.x += dpp_mov<0x12C>(t.x); t.y += dpp_mov<0x12C>(t.y); t.z += dpp_mov<0x12C>(t.z); t.w += dpp_mov<0x12C>(t.w);   // row_ror:12 = lane + 4
-            CSTAMP(4);                              // row update
+            CSTAMP(3);                              // H0: row update + tile sums done
             if (last) {                             // hand the state back to the ordinary buffers
                 if (hfin) {
                     C3D_HROW_INDEX;
@@ -262,14 +261,11 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 __builtin_amdgcn_raw_buffer_store_b128(o1, rsrc, (u0 + 1) * 16, 0, 0);
             }
         }
-#ifdef C3D_STAMPS
-        if (last && stamper && lane == 0) for (int k = 0; k < 10; ++k) g_cstamps[k] = cacc[k];
-#endif
         if (last) return;
         if (solo) continue;
-        CSTAMP(6);                                  // publish
-        // B3: nobody polls before this workgroup's own record is out — fifteen spinning waves would take the issue
-        // slots H0's update needs, and no gather can finish earlier than that anyway
+        CSTAMP(4);                                  // H0: record stored
+        // B3: nobody polls before this workgroup's own record is out: no gather can finish earlier than that, and the
+        // spinning waves cost H0 issue slots (measured: 4.43 us per step with it, 4.53 without)
         __syncthreads();
         // ---- gather the replica's records of step s+1 into LDS: re-read until every tag matches ----------
         {
@@ -287,9 +283,6 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 #pragma unroll
                 for (int k = 0; k < KUMAX; ++k)
                     if (k < ku) ok &= v[k].x == tag && v[k].z == tag;
-#ifdef C3D_STAMPS
-                if (stamper) cacc[9] += 1;
-#endif
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
@@ -299,7 +292,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                     return;
                 }
             }
-            CSTAMP(7);                              // gather: sweeps until every tag matches
+            CSTAMP(5);                              // H0's gather complete
 #pragma unroll
             for (int k = 0; k < KUMAX; ++k)
                 if (k < ku) { smem[gda[k]] = __uint_as_float(v[k].y); smem[gdb[k]] = __uint_as_float(v[k].w); }
@@ -309,8 +302,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 }
 
 #ifdef C3D_STAMPS
-hipError_t read_debug_forces(float* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbgF), sizeof(float) * 2 * 6 * 1024); }
-hipError_t read_cluster_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamps), sizeof(unsigned long long) * 16); }
+hipError_t read_cluster_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamps), sizeof(unsigned long long) * 64 * 8); }
 #endif
 
 // ---- host side ---------------------------------------------------------------------------------------

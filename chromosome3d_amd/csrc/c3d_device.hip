@@ -153,7 +153,6 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
 }
 
 #ifdef C3D_STAMPS
-hipError_t read_debug_forces_step(float* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbgF), sizeof(float) * 2 * 6 * 1024); }
 hipError_t read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16); }
 #endif
 

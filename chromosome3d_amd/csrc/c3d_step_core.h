@@ -10,11 +10,6 @@
 
 namespace c3d {
 
-#ifdef C3D_STAMPS
-// diagnostic build: pair sum and chain sum of every row of replica 0 at the last evaluation, per kernel (0 k_step, 1 k_cluster)
-static __device__ float g_dbgF[2][6][1024];   // one copy per translation unit
-#endif
-
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
@@ -224,12 +219,6 @@ __device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevSte
         // lane r < 4 takes its own quad's sum if that is its row's, else the sum of lanes 4..7 (row_ror:12 = lane + 4)
         const float ox = dpp_mov<0x12C>(cx), oy = dpp_mov<0x12C>(cy), oz = dpp_mov<0x12C>(cz);
         const bool own = lane == rsel, other = lane == (rsel ^ 1);   // in lanes 0..3 rsel is the even-quad row of this pass
-#ifdef C3D_STAMPS
-        if (m.rep_base == 0 && blockIdx.y == 0 && lane < RPW && (own || other) && row0 + lane < 1024) {
-            g_dbgF[0][0][row0 + lane] = Fx; g_dbgF[0][1][row0 + lane] = Fy; g_dbgF[0][2][row0 + lane] = Fz;
-            g_dbgF[0][3][row0 + lane] = own ? cx : ox; g_dbgF[0][4][row0 + lane] = own ? cy : oy; g_dbgF[0][5][row0 + lane] = own ? cz : oz;
-        }
-#endif
         Fx += own ? cx : (other ? ox : 0.0f);
         Fy += own ? cy : (other ? oy : 0.0f);
         Fz += own ? cz : (other ? oz : 0.0f);

@@ -1,4 +1,6 @@
-"""Diagnostic: cycles per phase of one workgroup of the cluster kernel (libc3d_stamps.so)."""
+"""Diagnostic: time line of one step of the cluster kernel (libc3d_stamps.so): s_memrealtime stamps (100 MHz, 10 ns) of the
+last 64 steps of a launch, H0 of (replica 0, part 0) and compute wave 0 of the same workgroup; medians in microseconds
+since the step's start (H0 leaving barrier B1)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -10,22 +12,28 @@ import numpy as np
 s = Solver(0)
 L = lib.load()
 L.c3d_debug_cluster_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
-names = ["lds-write+loop", "B1 wait", "H0 sums+scalars", "B2 wait (compute waves)", "H0 row update", "-", "H0 publish", "B3 + gather wait", "-", "sweeps"]
-cases = [a.split(":") for a in sys.argv[1:]] or [("chr21_1mb", "20"), ("chr4_1mb", "20"), ("chr1_500kb", "3"), ("chr1_500kb", "20")]
+names = ["H0 scalars done", "H0 past B2 (compute waves done)", "H0 row update done", "H0 record stored", "H0 gather complete",
+         "next step starts", "compute wave 0 starts", "compute wave 0 done"]
+cases = [a.split(":") for a in sys.argv[1:]] or [("chr1_500kb", "20"), ("chr1_500kb", "8"), ("chr4_1mb", "20"), ("chr21_1mb", "20")]
 for cid, nrep in cases:
     nrep = int(nrep)
     IF = load_if(cid)
     s.set_model(default_model()); pipeline.IF2dist_new(s, IF)
     for kind, st in (("md", [(1, 4000, 0.005, 1.0, 0.01, 1.0, 300.0)]), ("fire", [(2, 4000, 0.0, 1.0, 1.0, 0.85, 0.0)])):
-        s.set_schedule(make_stages(st)); s.set_option("resident", 1); s.set_option("cluster", 1)
+        s.set_schedule(make_stages(st)); s.set_option("resident", 1)
         s.init_replicas(nrep, 1, 0)
         s.run_steps(200)
         K = 2000
         s.run_steps(K)
         ms, _, _ = s.last_timing()
-        buf = (C.c_ulonglong * 16)()
+        buf = (C.c_ulonglong * 512)()
         L.c3d_debug_cluster_stamps(buf)
-        a = np.array(buf[:10], dtype=np.float64) / K
-        txt = " | ".join(f"{n} {v:.0f}" for n, v in zip(names[:8], a[:8]))
-        print(f"{cid} {kind} nrep={nrep} parts={s.stat('cluster_parts'):.0f} rpw={s.stat('cluster_rows_per_wave'):.0f} path={s.stat('last_path'):.0f}: "
-              f"{1e3 * ms / K:.2f} us/step; cycles/step: {txt} | total {a[:8].sum():.0f}; sweeps/step {a[9]:.2f}", flush=True)
+        a = np.array(buf[:], dtype=np.float64).reshape(64, 8)
+        order = np.argsort(a[:, 0]); a = a[order]                      # by step start
+        t0 = a[:-1, 0:1]
+        rel = np.concatenate([a[:-1, 1:6] - t0, a[1:, 0:1] - t0, a[:-1, 6:8] - t0], axis=1) * 0.01     # us
+        med = np.median(rel[2:-2], axis=0)
+        print(f"{cid} {kind} nrep={nrep} parts={s.stat('cluster_parts'):.0f} cw={s.stat('cluster_compute_waves'):.0f} rpw={s.stat('cluster_rows_per_wave'):.0f}: "
+              f"{1e3 * ms / K:.2f} us/step")
+        for n_, v in zip(names, med):
+            print(f"      {v:6.2f} us  {n_}")
