@@ -89,6 +89,9 @@ struct c3d_ctx {
     hipEvent_t gev[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t kev0 = nullptr, kev1 = nullptr;     // kernel_timing: the multi-step kernel's own start / end
+    int kernel_timing = 0;
+    double last_kernel_ms = 0;
 
     int n = 0, npad = 0, ntiles = 0, nrep = 0, R = 0;
     c3d_model model;
@@ -370,12 +373,19 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     ++c->cl_seq;
     if (c->inject_timeout) { *c->h_tmo = 1; c->inject_timeout = false; }
     const c3d::DevModel m = dev_model(c);
-    hipError_t e = c3d::launch_cluster(m, dev_fire(c), c->cl_plan, c->d_io + c->parity, c->buf.tgt, c->d_crec, c->d_prog,
+    c3d::ClusterPlan pl = c->cl_plan;
+    if (c->kernel_timing) { pl.t0 = c->kev0; pl.t1 = c->kev1; }
+    hipError_t e = c3d::launch_cluster(m, dev_fire(c), pl, c->d_io + c->parity, c->buf.tgt, c->d_crec, c->d_prog,
                                        c->op_run[c->pc], c->op_skip[c->pc], (int)nops, seq << 20, c->h_tmo_dev,
                                        c->d_claim + 8 * seq, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("cluster launch: ") + hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(c->stream));
     ++c->cluster_launches;
+    if (c->kernel_timing) {
+        float kms = 0;
+        HIP_TRY(hipEventElapsedTime(&kms, c->kev0, c->kev1));
+        c->last_kernel_ms += kms;
+    }
     if (launch_was_abandoned(c)) { *ran = false; return C3D_OK; }
     *ran = true;
     c->last_path = 2;
@@ -490,7 +500,7 @@ int run_ops(c3d_ctx* c, size_t nops) {
 }
 
 int begin_timing(c3d_ctx* c) {
-    c->last_ms = 0; c->last_steps = 0; c->last_launches = 0;
+    c->last_ms = 0; c->last_kernel_ms = 0; c->last_steps = 0; c->last_launches = 0;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     return C3D_OK;
 }
@@ -605,6 +615,7 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     c3d_default_schedule(c->stages.data(), (int)c->stages.size(), 3000);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+              hipEventCreate(&c->kev0) == hipSuccess && hipEventCreate(&c->kev1) == hipSuccess &&
               hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
     c->gstream[0] = c->stream;
     for (int g = 1; ok && g < c3d_ctx::kMaxGroups; ++g)
@@ -636,6 +647,8 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
     if (c->h_tmo) (void)hipHostFree(c->h_tmo);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->kev0) hipEventDestroy(c->kev0);
+    if (c->kev1) hipEventDestroy(c->kev1);
     for (int g = 1; g < c3d_ctx::kMaxGroups; ++g) {
         if (c->gstream[g]) hipStreamDestroy(c->gstream[g]);
         if (c->gev[g]) hipEventDestroy(c->gev[g]);
@@ -684,6 +697,7 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         drop_graphs(c);
         return C3D_OK;
     }
+    if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0; return C3D_OK; }
     if (!strcmp(key, "resident")) { c->resident = value < 0 ? -1 : (value != 0); c->resident_skip = 0; return C3D_OK; }
     if (!strcmp(key, "precision")) {       // 32 (the product kernels) or 64 (the fp64 reference step); call before c3d_init_replicas
         if (value != 32 && value != 64) return fail(C3D_ERR_INVALID, "precision must be 32 or 64");
@@ -1108,6 +1122,7 @@ extern "C" int c3d_last_timing(const c3d_ctx* c, double* ms_total, long* steps, 
 extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     if (!c || !key || !value) return fail(C3D_ERR_INVALID, "c3d_get_stat: null argument");
     if (!strcmp(key, "graph_captures")) *value = (double)c->graph_captures;
+    else if (!strcmp(key, "last_kernel_us")) *value = 1e3 * c->last_kernel_ms;
     else if (!strcmp(key, "graph_launches")) *value = (double)c->graph_launches;
     else if (!strcmp(key, "graphs_cached")) *value = (double)c->graphs.size();
     else if (!strcmp(key, "step_launches")) *value = (double)c->step_launches;

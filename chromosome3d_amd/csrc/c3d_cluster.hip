@@ -27,6 +27,7 @@
 // here ends in the bits of the per-step path.  Every spin is bounded; a workgroup that gives up sets *timeout and the
 // host re-runs the range step by step (the launch only writes its outputs in its last step).
 // Deck: chromosome3D.pl:1646-1700 (hot MD), :1729-1782 (cooling), :1790-1803 (minimisation).
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 
@@ -368,8 +369,12 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_cluster<POT, RPW, NB, RS1>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
-                       run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, m, fp);
+    if (pl.t0 && pl.t1)
+        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, RS1>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
+                              reinterpret_cast<u32x4*>(rec), runs, run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, m, fp);
+    else
+        hipLaunchKernelGGL((k_cluster<POT, RPW, NB, RS1>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
+                           run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, m, fp);
     return hipGetLastError();
 }
 template <int POT>

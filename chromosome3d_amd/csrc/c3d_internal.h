@@ -102,6 +102,7 @@ AnnealIO anneal_io(const DevBuffers& b, int parity);
 struct ClusterPlan {
     int rpw, cw, helpers, wgs_per_cu, parts, per_xcd, grid, threads, units, device;
     size_t lds;
+    hipEvent_t t0 = nullptr, t1 = nullptr;        // when set: the launch stamps them with the kernel's own start and end
 };
 bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan);
 size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl);

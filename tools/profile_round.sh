@@ -1,0 +1,25 @@
+#!/bin/bash
+# Profiles of the round, on the GPU box (outputs under gpurun_out/<tag>/, to be copied into profiles/):
+#   kernel traces of the two bench commands (default and the driver's --steps 20 --warmup 5) and the HBM-traffic counters of the
+#   headline kernel (separate --pmc passes, as MI355X_MICROARCH.md prescribes).    bash tools/profile_round.sh r02 [traces]
+set -e
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG/prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/trace_default -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/bench_default_under_rocprof.json 2> $O/trace_default.log
+rocprofv3 --kernel-trace --stats -d $O/trace_s20 -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_s20_under_rocprof.json 2> $O/trace_s20.log
+if [ "$2" != "traces" ]; then
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/tools/pmc_run_cluster.py 20 > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/tools/pmc_run_cluster.py 20 > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_sq -o p --output-format csv -- python3 $R/tools/pmc_run_cluster.py 20 > $O/pmc_sq.log 2>&1
+cd $R
+python tools/pmc_summarise.py $O/pmc_fetch $O/pmc_write k_cluster --json $O/hbm_traffic_k_cluster.json --n 455 --replicas 20 --steps-per-dispatch 2000 > $O/pmc_hbm_summary.txt
+python tools/pmc_summarise.py $O/pmc_sq k_cluster > $O/pmc_sq_summary.txt
+fi
+cd $R
+python tools/trace_check.py $O/trace_default/t_kernel_stats.csv $O/bench_default_under_rocprof.json $O/trace_s20/t_kernel_stats.csv $O/bench_s20_under_rocprof.json > $O/trace_vs_bench.txt
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_s20.json 2> $O/bench_s20.err
+echo done

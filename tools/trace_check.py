@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Does a rocprofv3 kernel trace agree with the bench line taken under it?
+
+    python tools/trace_check.py <trace_dir>/t_kernel_stats.csv <bench.json> [...pairs]
+
+Prints, per pair, the step kernel's average duration in the trace next to `roofline.avg_launch_us`, and the trace's
+total time of that kernel per SA step next to `us_per_step_kernel` (the trace holds every launch of the process, the
+bench line the timed regions only; `process_totals` is what connects the two)."""
+import csv
+import json
+import sys
+
+
+def bench_line(path):
+    for line in open(path):
+        line = line.strip()
+        if line.startswith("{") and '"metric"' in line:
+            return json.loads(line)
+    raise SystemExit(f"{path}: no bench line")
+
+
+def main(argv):
+    for stats, bench in zip(argv[0::2], argv[1::2]):
+        b = bench_line(bench)
+        name = b["roofline"]["kernel"].split("<")[0].split("::")[-1]
+        rows = [r for r in csv.DictReader(open(stats)) if name in r["Name"]]
+        calls = sum(int(r["Calls"]) for r in rows)
+        total_us = sum(float(r["TotalDurationNs"]) for r in rows) / 1e3
+        t = b["process_totals"]
+        print(f"{bench}: --steps {b['steps']} --warmup {b['warmup']}  kernel {b['roofline']['kernel']}")
+        print(f"  trace : {calls} launches, average {total_us / calls:.2f} us, total {total_us / 1e3:.3f} ms"
+              f" -> {total_us / t['sa_steps']:.4f} us per SA step over the {t['sa_steps']} steps of the process")
+        print(f"  bench : roofline.avg_launch_us {b['roofline']['avg_launch_us']:.2f} ({b['roofline']['launches_per_region']} launches per region),"
+              f" us_per_step_kernel {b['us_per_step_kernel']:.4f}, us_per_step_device (event-bracketed region) {b['us_per_step_device']:.4f}")
+        print(f"  ratio : per-step trace / bench = {total_us / t['sa_steps'] / b['us_per_step_kernel']:.4f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
