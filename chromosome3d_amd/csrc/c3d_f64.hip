@@ -6,9 +6,9 @@
 //   k64_force    one wave per (replica, row): every term of the row's force, fp64 tree sum over the lanes
 //   k64_update   one workgroup per replica: the replica sums, thermostat / FIRE state, new velocities and positions
 // It puts a number on what fp32 costs (bench.py --dtype f64 prints the f64 line beside the f32 one) and, because the
-// CPU oracle is the same algorithm in the same precision, it ties the GPU to the oracle over LONG trajectories (fp32
+// CPU restatement the tests hold is the same algorithm in the same precision, it ties the GPU to it over LONG trajectories (fp32
 // trajectories leave any reference after a few hundred chaotic steps; tests/test_gpu_parity.py::test_fp64_path_*).
-// Targets come from the integer tenths (0.1 * t10, as the oracle forms them), not from the fp32 target matrix.
+// Targets come from the integer tenths (0.1 * t10, as the CPU restatement forms them), not from the fp32 target matrix.
 #include "c3d_internal.h"
 
 namespace c3d {
@@ -32,7 +32,7 @@ struct FireState64 {
 };
 constexpr double kBoltz64 = 0.0019872, kAccel64 = 418.4;
 
-// dE/dDelta of the NOE term without S and w (the oracle's softsq, oracle/... restated)
+// dE/dDelta of the NOE term without S and w
 __device__ __forceinline__ double noe_grad64(const Model64& m, double delta) {
     const double ad = fabs(delta);
     if (m.noe_pot == 0) { if (ad > m.rs) { const double g = m.tail_c - m.tail_b / (ad * ad); return delta > 0 ? g : -g; } return 2.0 * delta; }

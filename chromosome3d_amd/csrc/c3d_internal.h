@@ -116,7 +116,7 @@ size_t sym_scratch_floats(const DevModel& m);
 void sym_tile_list(const DevModel& m, int2* out);
 hipError_t launch_step_sym(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int parity, const void* tiles,
                            float* scratch, hipStream_t s);
-// fp64 step (c3d_f64.hip, option "precision" = 64): the oracle's algorithm in the oracle's precision on the GPU.
+// fp64 step (c3d_f64.hip, option "precision" = 64): the CPU restatement's algorithm in its precision on the GPU.
 // model_host[14] = s_noe, rswitch, asym, masym, mrswitch, k_bond, b0, k_ang, a0, r0_rep, k_rep, mass, fbeta, min_sep;
 // step_host[6] = kind, dt, w_all, w_vdw, repel_s, t_bath; fire_host[7] = dt_start, dt_max, f_inc, f_dec, alpha_start, f_alpha, max_step.
 // X, V, F, Vinit: [nrep][n][3] doubles; L: [nrep][4]; fs: nrep * fire_state64_bytes(); t10: n*n tenths of an Angstrom.

@@ -16,7 +16,7 @@
 //                 then the same step scalars / row update / 8-row tile sums as k_step (c3d_step_core.h).
 //
 // No atomics, no inter-workgroup hand-off inside a launch: deterministic, independent of placement and GPU count.  The
-// summation order differs from k_step's (so do the last bits); parity is against the fp64 oracle (tests/test_gpu_large.py).
+// summation order differs from k_step's (so do the last bits); parity is checked in fp64 by tests/test_gpu_large.py.
 // Slabs: rowpart [replica][Q][3][npad], colpart [replica][G][3][npad], Q = npad / 256, G = ceil(n / 64): 1.5 MB per
 // replica at N = 2500, written and read once per step.
 #include "c3d_step_core.h"
