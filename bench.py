@@ -200,38 +200,52 @@ def main():
 
     # ---- the benchmark's call pattern: init, W warm-up steps, `reps` regions of K steps -----------------------
     def pattern(timed):
-        batch = 0
+        # the schedule position is tracked here, so that inside the clock there is nothing but c3d_run_steps
+        batch, pos = 0, 0
         s.init_replicas(M, 82364, first)
         left_w = args.warmup
         while left_w > 0:
-            if s.steps_done >= L:
+            if pos >= L:
                 batch += 1
+                pos = 0
                 s.init_replicas(M, 82364, batch * total_replicas + first)
-            did = s.run_steps(min(left_w, L - s.steps_done))
+            did = s.run_steps(min(left_w, L - pos))
             left_w -= did
+            pos += did
             totals["sa_steps"] += did
             totals["launches"] += s.last_timing()[2]
         walls, devs, kerns, launches = [], [], [], 0
         for _ in range(reps):
+            # a region that would cross the end of the schedule starts a fresh batch of replicas first (untimed)
+            if pos + args.steps > L and args.steps <= L:
+                batch += 1
+                pos = 0
+                s.init_replicas(M, 82364, batch * total_replicas + first)
             if timed:
                 sync_all()
-            t0 = time.perf_counter()
-            left, dev, kern = args.steps, 0.0, 0.0
+            wall, left, dev, kern = 0.0, args.steps, 0.0, 0.0
             while left > 0:
-                if s.steps_done >= L:
+                if pos >= L:                                              # only when --steps exceeds the schedule
                     batch += 1
+                    pos = 0
                     s.init_replicas(M, 82364, batch * total_replicas + first)
-                did = s.run_steps(min(left, L - s.steps_done))         # synchronises the solver stream
+                want = min(left, L - pos)
+                t0 = time.perf_counter()
+                did = s.run_steps(want)                                   # synchronises the solver stream
+                wall += time.perf_counter() - t0
                 left -= did
+                pos += did
                 ms, _, la = s.last_timing()
                 dev += ms
                 kern += s.stat("last_kernel_us")
                 launches += la
                 totals["sa_steps"] += did
                 totals["launches"] += la
-            if timed:
+            if timed and dist is not None:
+                t0 = time.perf_counter()
                 sync_all()
-            walls.append(time.perf_counter() - t0)
+                wall += time.perf_counter() - t0
+            walls.append(wall)
             devs.append(dev)
             kerns.append(kern)
         return walls, devs, kerns, launches
@@ -239,13 +253,16 @@ def main():
     pattern(False)                                # untimed: every graph the pattern needs exists afterwards
     cap0 = s.stat("graph_captures")
     fb0 = s.stat("resident_fallbacks")
-    walls, devs, _, launches = pattern(True)
+    s.set_option("event_timing", 0)               # nothing but launch + synchronise inside the clock (an event pair costs 2-5 us per call)
+    walls, _, _, launches = pattern(True)
+    s.set_option("event_timing", 1)
     captures_in_timed = s.stat("graph_captures") - cap0
     fallbacks_in_timed = s.stat("resident_fallbacks") - fb0
-    # the same regions once more, untimed by the metric, with the multi-step kernel's own start/end stamps switched on
-    # (hipExtLaunchKernel events on the solver's stream; they cost ~15 us of host time per launch, so not above)
+    # the same regions once more, untimed by the metric, for the device-side durations: the HIP-event pair around each call
+    # and the multi-step kernel's own start/end stamps (hipExtLaunchKernel events on the solver's stream; ~15 us of host
+    # time per launch, so not above)
     s.set_option("kernel_timing", 1)
-    _, _, kerns, _ = pattern(False)
+    _, devs, kerns, _ = pattern(False)
     s.set_option("kernel_timing", 0)
     assert captures_in_timed == 0, f"{captures_in_timed} hipGraph captures inside the timed regions"
     kernel = s.step_kernel_name

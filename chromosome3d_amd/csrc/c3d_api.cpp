@@ -92,6 +92,8 @@ struct c3d_ctx {
     hipEvent_t kev0 = nullptr, kev1 = nullptr;     // kernel_timing: the multi-step kernel's own start / end
     int kernel_timing = 0;
     double last_kernel_ms = 0;
+    int event_timing = 1;                          // 0: no event pair around c3d_run_steps / c3d_run (c3d_last_timing then reports 0 ms)
+    bool ev1_recorded = false;                     // the closing event of the timed range already sits behind the last launch
 
     int n = 0, npad = 0, ntiles = 0, nrep = 0, R = 0;
     c3d_model model;
@@ -379,14 +381,16 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
                                        c->op_run[c->pc], c->op_skip[c->pc], (int)nops, seq << 20, c->h_tmo_dev,
                                        c->d_claim + 8 * seq, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("cluster launch: ") + hipGetErrorString(e));
+    if (c->event_timing) HIP_TRY(hipEventRecord(c->ev1, c->stream));    // closes the timed range unless more work follows (end_timing)
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->ev1_recorded = true;
     ++c->cluster_launches;
     if (c->kernel_timing) {
         float kms = 0;
         HIP_TRY(hipEventElapsedTime(&kms, c->kev0, c->kev1));
         c->last_kernel_ms += kms;
     }
-    if (launch_was_abandoned(c)) { *ran = false; return C3D_OK; }
+    if (launch_was_abandoned(c)) { *ran = false; c->ev1_recorded = false; return C3D_OK; }
     *ran = true;
     c->last_path = 2;
     account_ops(c, nops);
@@ -396,6 +400,7 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
 // fp64 reference path: one force launch + one update launch per op on the context's stream; the fp32 buffers of the
 // current parity receive a copy of the state afterwards (read-back, energies, scoring, the minimiser's exit test)
 int run_ops64(c3d_ctx* c, size_t nops) {
+    c->ev1_recorded = false;
     const c3d::DevModel m = dev_model(c);
     const c3d_model& h = c->model;
     const double mh[14] = {h.s_noe, h.rswitch, h.asym, h.masym, h.mrswitch, h.k_bond, h.b0, h.k_ang, h.a0, h.r0_rep, h.k_rep, h.mass, h.fbeta,
@@ -431,6 +436,7 @@ int run_ops(c3d_ctx* c, size_t nops) {
         if (rc != C3D_OK || ran) return rc;
     }
     c->last_path = 0;
+    c->ev1_recorded = false;
     const int G = active_groups(c);
     // every replica group advances on its own stream (fork from / join into stream 0 around the range): while one
     // group sits in its launch boundary the other computes
@@ -501,12 +507,16 @@ int run_ops(c3d_ctx* c, size_t nops) {
 
 int begin_timing(c3d_ctx* c) {
     c->last_ms = 0; c->last_kernel_ms = 0; c->last_steps = 0; c->last_launches = 0;
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    c->ev1_recorded = false;
+    if (c->event_timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
     return C3D_OK;
 }
 int end_timing(c3d_ctx* c) {
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->ev1_recorded) {                        // a multi-step launch has recorded it behind itself and synchronised already
+        if (c->event_timing) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (!c->event_timing) return C3D_OK;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
@@ -697,6 +707,7 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         drop_graphs(c);
         return C3D_OK;
     }
+    if (!strcmp(key, "event_timing")) { c->event_timing = value != 0; return C3D_OK; }
     if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0; return C3D_OK; }
     if (!strcmp(key, "resident")) { c->resident = value < 0 ? -1 : (value != 0); c->resident_skip = 0; return C3D_OK; }
     if (!strcmp(key, "precision")) {       // 32 (the product kernels) or 64 (the fp64 reference step); call before c3d_init_replicas
@@ -1101,6 +1112,7 @@ extern "C" int c3d_run(c3d_ctx* c) {
     }
     hipError_t e = c3d::launch_centre(dev_model(c), c->buf, c->parity, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("centre launch: ") + hipGetErrorString(e));
+    c->ev1_recorded = false;                       // work was queued behind the last multi-step launch
     rc = end_timing(c);
     if (rc) return rc;
     // a blown-up trajectory (NaN/Inf) must not reach the caller as a "model"
