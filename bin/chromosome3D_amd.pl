@@ -62,6 +62,15 @@ unlink map { "$dir_out/$_" } ("$ID.dist", "$ID.rr", "contact.tbl", "job.sh", "jo
 copy($file_if, "$dir_out/$ID.txt") or die "ERROR! cannot copy $file_if: $!\n" if abs_path($file_if) ne (abs_path("$dir_out/$ID.txt") || "");
 chdir $dir_out or die $!;
 
+# <ID>.fasta (:92-98): one residue per bead.  Every bead is written as MET, as in the bundled output_models, so the
+# sequence file that goes with the models is M x L (the reference cuts L letters out of a fixed pseudo-protein)
+{
+	my $L = first_line_fields("$ID.txt");
+	open my $fa, ">", "$ID.fasta" or die $!;
+	print $fa ">$ID\n", "M" x $L, "\n";
+	close $fa;
+}
+
 # (B) build models
 my $restraints;
 if ($have_xs) {

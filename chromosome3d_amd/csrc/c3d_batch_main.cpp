@@ -69,6 +69,10 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job) {
     const std::string tbl = dir + "/contact.tbl";
     TRY(c3d_write_front_half(d10.data(), n, model.min_sep, (dir + "/" + job.id + ".dist").c_str(), (dir + "/" + job.id + ".rr").c_str(),
                              tbl.c_str(), &R));
+    {   // <ID>.fasta (:92-98): one residue per bead, every bead MET as in the bundled output_models
+        FILE* fa = fopen((dir + "/" + job.id + ".fasta").c_str(), "w");
+        if (fa) { fprintf(fa, ">%s\n%s\n", job.id.c_str(), std::string((size_t)n, 'M').c_str()); fclose(fa); }
+    }
     std::vector<c3d_stage> stages(c3d_default_schedule(nullptr, 0, o.min_steps));
     c3d_default_schedule(stages.data(), (int)stages.size(), o.min_steps);
     c3d_fire_params fire;

@@ -77,6 +77,7 @@ def test_perl_driver_same_cli_and_outputs(built, tmp_path):
         assert out.returncode == 0, out.stdout + out.stderr
         assert ("through the C3D XS binding" in out.stdout) == (have_xs and force_cli == "0")
         cid = "chr21_1mb_matrix"
+        assert open(od / f"{cid}.fasta").read() == f">{cid}\n" + "M" * 37 + "\n"      # :92-98, one MET per bead
         for f in (f"{cid}.txt", f"{cid}.dist", f"{cid}.rr", "contact.tbl", "job.log", "model_info.log"):
             assert (od / f).exists(), f
         assert open(od / "contact.tbl", "rb").read() == open(os.path.join(GOLD, "chr21_1mb.contact.tbl"), "rb").read()
