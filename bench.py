@@ -90,6 +90,26 @@ def cpu_baseline(IF, d10, model, fire, stages, budget_s=8.0):
     return one[0], one[1], all_cores
 
 
+def measured_stream_peaks():
+    """The HBM stream rates measured on this machine type (tools/microbench/hbm_stream.hip), from the newest
+    profiles/*hbm_stream*.txt: {"read": GB/s, "copy": GB/s, "triad": GB/s, "source": file} or None."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_stream*.txt")))
+    if not files:
+        return None
+    out = {}
+    for line in open(files[-1]):
+        mm = re.match(r"(read|copy|triad)\s.*best (\d+) GB/s", line)
+        if mm:
+            out[mm.group(1)] = float(mm.group(2))
+    if not out:
+        return None
+    out["unit"] = "GB/s"
+    out["source"] = os.path.relpath(files[-1], ROOT)
+    return out
+
+
 def hbm_traffic_from_profiles(kernel, n, replicas):
     """HBM bytes per SA step of `kernel` from the newest profiles/*hbm_traffic*.json that matches (written by
     tools/pmc_summarise.py from separate rocprofv3 --pmc passes); None when there is none."""
@@ -342,9 +362,16 @@ def main():
                          "launches_per_region": round(launches_per_region, 2),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch),
                          "algorithmic_bytes_per_sa_step": M * B,
+                         "peak_measured": measured_stream_peaks(),
                          "note": "B = 4R + 72N per replica-step (SURVEY 8d) x replicas on this GPU; duration = the kernel's own start-to-end "
                                  "stamps (hipExtLaunchKernel events on the solver's stream, taken in a replay of the timed regions; median region / launches per region); the kernel is VALU-issue bound (DESIGN 5), the target "
                                  "matrix lives in registers / L2, so fabric traffic is below B by design"},
+            # SURVEY 8d's secondary figure: the path is O(N^2) VALU work on L2-resident targets, so the low HBM fraction
+            # is explained by the vector-ALU rate: algorithmic flops (30 R + 40 N per replica-step) against the fp32 vector peak
+            "valu": {"flops_per_replica_step": 30 * R + 40 * n,
+                     "achieved_tflops": round(M * (30 * R + 40 * n) / (kernel_us_region / args.steps * 1e-6) / 1e12, 2),
+                     "peak_tflops": 157.3, "pairs_evaluated_per_replica_step": n * (-(-n // 256) * 256),
+                     "note": "every pair is evaluated from both of its rows (16 VALU instructions each); peak = fp32 vector spec"},
             "gather_ms": round(gather_ms, 3),
             "models_ranked": len(order),
             "spearman_if_invd_best_ranked": round(-float(allrec[order[0], 2]), 4),
