@@ -42,6 +42,17 @@ int main(int argc, char** argv) {
     REQ(c3d_write_pdb((tmp + "/m.pdb").c_str(), xyz, n, 1.0, 2.0, 3.0, "m.pdb") == C3D_OK);
     float* back = nullptr;
     REQ(c3d_read_pdb_ca((tmp + "/m.pdb").c_str(), &back, &m) == C3D_OK && m == n);
+    // output shaping (in place and to a second file, with and without the log), model reduction, similarity
+    REQ(c3d_shape_pdb((tmp + "/m.pdb").c_str(), (tmp + "/shaped.pdb").c_str(), (tmp + "/model_info.log").c_str()) == C3D_OK);
+    REQ(c3d_shape_pdb((tmp + "/m.pdb").c_str(), (tmp + "/m.pdb").c_str(), nullptr) == C3D_OK);
+    REQ(c3d_shape_pdb((tmp + "/nope.pdb").c_str(), (tmp + "/x.pdb").c_str(), nullptr) != C3D_OK);
+    {
+        std::vector<double> xd((size_t)3 * n), red((size_t)3 * ((n + 1) / 2));
+        for (int i = 0; i < 3 * n; ++i) xd[i] = xyz[i];
+        REQ(c3d_reduce_model(xd.data(), n, red.data()) == C3D_OK);
+        double sp = 0, rm = 0;
+        REQ(c3d_model_similarity(xd.data(), xd.data(), n, &sp, &rm) == C3D_OK && sp > 0.999999 && rm < 1e-9);
+    }
     // error paths must not leak or crash
     { double* none = nullptr; int nn = 0; REQ(c3d_parse_if_file((tmp + "/does-not-exist").c_str(), &none, &nn) != C3D_OK); }
     int32_t *xi = nullptr, *xj = nullptr, *xt = nullptr;
