@@ -1,6 +1,6 @@
 // c3d_cluster.hip — K3/K4 as ONE launch for many SA steps: a replica on a few LARGE workgroups of ONE XCD (gfx950).
 //
-// The solver is bound by VALU issue (a wave64 instruction holds its SIMD ~4 cycles: tools/microbench/valu_rate and the
+// The solver is bound by the vector ALU (a pair term is ~27 ns of VALU pipe per SIMD: tools/microbench/valu_forms, pair_loop_insitu, and the
 // SQ counters in profiles/), so a step costs what its instruction count costs — and in a kernel where every wave also
 // reduces the replica sums, evaluates chain terms, updates rows and handles records, that overhead is as large as the
 // pair loop.  Here the waves of a workgroup are specialised:

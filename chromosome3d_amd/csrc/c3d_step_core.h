@@ -114,7 +114,7 @@ __device__ __forceinline__ void tile_prefetch(const DevModel& m, const float* __
 }
 
 // One pair term.  F_i += c * (x_i - x_j) with c = -(dE/dd)/d.  Written to minimise VALU issue slots: the solver is
-// bound by VALU issue (one wave64 instruction holds its SIMD ~4 cycles; tools/microbench/valu_rate), so every
+// bound by the vector ALU (a wave issues one VALU instruction per ~5 ns, the pipe takes 1.2-3.5 ns per instruction by its form; tools/microbench/valu_forms), so every
 // instruction of this function costs ~1.4 ns x pairs / lanes on the whole chip:
 //   r2 carries a +1e-12 guard inside the fma chain (no separate max);
 //   NOE, CNS-default tail (slope 2 rs): with u = (d - t)/d = 1 - t/d the clamp of the soft-square acts on
