@@ -19,6 +19,11 @@
 #define FMAK(D, A, B, C) "v_fmaak_f32 v" #D ", v" #A ", v" #B ", 0x2b8cbccc\n"
 #define MED3(D, A, B, C) "v_med3_f32 v" #D ", v" #A ", v" #B ", v" #C "\n"
 #define RSQ(D, A, B, C) "v_rsq_f32_e32 v" #D ", v" #A "\n"
+#define FMAC_DPP(D, A, B, C) "v_fmac_f32_dpp v" #D ", v" #A ", v" #B " quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf\n"
+#define MUL_DPP(D, A, B, C) "v_mul_f32_dpp v" #D ", v" #A ", v" #B " quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf\n"
+#define FMA_SQ3(D, A, B, C) "v_fma_f32 v" #D ", v" #A ", v" #A ", v" #C "\n"
+#define FMAK_SQ(D, A, B, C) "v_fmaak_f32 v" #D ", v" #A ", v" #A ", 0x2b8cbccc\n"
+#define MUL_SDWA(D, A, B, C) "v_mul_f32_sdwa v" #D ", v" #A ", v" #B " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
 #define CLOB "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
              "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "s20"
 
@@ -39,6 +44,13 @@ template <int F> __global__ __launch_bounds__(256) void k(float* out, int iters)
         if constexpr (F == 10) asm volatile(REP16(FMAK, 20, 21, 0) ::: CLOB);        // literal addend
         if constexpr (F == 11) asm volatile(REP16(MED3, 20, 21, 22) ::: CLOB);
         if constexpr (F == 12) asm volatile(REP16(RSQ, 20, 0, 0) ::: CLOB);
+        if constexpr (F == 13) asm volatile(REP16(FMAC_DPP, 20, 20, 0) ::: CLOB);   // square through the DPP path
+        if constexpr (F == 14) asm volatile(REP16(FMAC_DPP, 20, 21, 0) ::: CLOB);
+        if constexpr (F == 15) asm volatile(REP16(MUL_DPP, 20, 20, 0) ::: CLOB);
+        if constexpr (F == 16) asm volatile(REP16(FMA_SQ3, 20, 0, 22) ::: CLOB);     // VOP3 a*a + c, c in another bank
+        if constexpr (F == 17) asm volatile(REP16(FMAK_SQ, 20, 0, 0) ::: CLOB);
+        if constexpr (F == 18) asm volatile(REP16(MUL_SDWA, 20, 20, 0) ::: CLOB);
+        if constexpr (F == 19) asm volatile(REP16(FMAC, 20, 24, 0) ::: CLOB);       // fmac, sources in one bank, different registers
     }
     float r;
     asm volatile("v_add_f32 %0, v40, v55" : "=v"(r) :: CLOB);
@@ -52,9 +64,10 @@ int main() {
     const int iters = 20000;
     const char* names[] = {"v_fma_f32 d,a,b,c   banks 0 1 2", "v_fma_f32 d,a,b,c   banks 0 0 0", "v_fma_f32 d,a,b,c   banks 0 1 1", "v_fma_f32 d,a,b,d (VOP3 acc)",
                            "v_fmac_f32 d,a,b (VOP2)", "v_fmac_f32 d,a,a", "v_mul_f32 d,a,b", "v_mul_f32 d,s,b", "v_sub_f32 d,s,b", "v_fma_f32 d,s,b,c",
-                           "v_fmaak_f32 d,a,b,lit", "v_med3_f32 d,a,b,c", "v_rsq_f32 d,a"};
-    for (int wps : {4, 3, 1})
-        for (int f = 0; f < 13; ++f) {
+                           "v_fmaak_f32 d,a,b,lit", "v_med3_f32 d,a,b,c", "v_rsq_f32 d,a", "v_fmac_f32_dpp d,a,a (identity)", "v_fmac_f32_dpp d,a,b (identity)",
+                           "v_mul_f32_dpp d,a,a (identity)", "v_fma_f32 d,a,a,c", "v_fmaak_f32 d,a,a,lit", "v_mul_f32_sdwa d,a,a", "v_fmac_f32 d,a,b  banks 0 0"};
+    for (int wps : {4, 3})
+        for (int f = 0; f < 20; ++f) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0));
@@ -64,7 +77,10 @@ int main() {
                     case 3: k<3><<<g, b>>>(out, iters); break; case 4: k<4><<<g, b>>>(out, iters); break; case 5: k<5><<<g, b>>>(out, iters); break;
                     case 6: k<6><<<g, b>>>(out, iters); break; case 7: k<7><<<g, b>>>(out, iters); break; case 8: k<8><<<g, b>>>(out, iters); break;
                     case 9: k<9><<<g, b>>>(out, iters); break; case 10: k<10><<<g, b>>>(out, iters); break; case 11: k<11><<<g, b>>>(out, iters); break;
-                    default: k<12><<<g, b>>>(out, iters); break;
+                    case 12: k<12><<<g, b>>>(out, iters); break; case 13: k<13><<<g, b>>>(out, iters); break; case 14: k<14><<<g, b>>>(out, iters); break;
+                    case 15: k<15><<<g, b>>>(out, iters); break; case 16: k<16><<<g, b>>>(out, iters); break; case 17: k<17><<<g, b>>>(out, iters); break;
+                    case 18: k<18><<<g, b>>>(out, iters); break;
+                    default: k<19><<<g, b>>>(out, iters); break;
                 }
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
