@@ -155,7 +155,7 @@ struct c3d_ctx {
 
     long k1_recomputed = 0, k1_patched = 0;   // K1: near-tie elements redone on the host in the reference's order / changed by it
     long graph_captures = 0, graph_launches = 0, step_launches = 0, resident_launches = 0, cluster_launches = 0;
-    int last_path = 0;                     // 0 per-step, 1 k_anneal, 2 k_cluster (what the last run_ops used)
+    int last_path = 0;                     // 0 per-step, 2 k_cluster, 3 fp64 reference (what the last run_ops used)
 
     double last_ms = 0;
     long last_steps = 0, last_launches = 0;

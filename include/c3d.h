@@ -104,12 +104,19 @@ int c3d_num_restraints(const c3d_ctx* ctx);
 int c3d_set_model(c3d_ctx* ctx, const c3d_model* m);
 int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const c3d_fire_params* fire,
                      float gtol, int check_every);
-/* Execution knobs (results do not depend on them except rows_per_wave, which changes summation order):
- *   resident        -1 (default) / 0 / 1: run step ranges as ONE resident launch (c3d_resident.hip) where that
- *                   is faster (small and medium N) / never / whenever the workgroups fit on the GPU
+/* Execution knobs.  The three launch forms (many steps per launch, one launch per step, symmetric tiles) and every setting
+ * of the knobs below except `precision`, `symmetric` and `start` end in the same bits.
+ *   resident        -1 (default) / 0 / 1: run step ranges as ONE multi-step launch of the cluster kernel (c3d_cluster.hip)
+ *                   wherever a geometry exists / never / as -1, without the back-off after an abandoned launch
+ *   cluster         0: never use the cluster kernel (test knob)
+ *   precision       32 (default) or 64: the fp64 reference kernels (c3d_f64.hip); call before c3d_init_replicas
+ *   symmetric       1: symmetric-tile kernels for large N (c3d_sym.hip; opt-in); call before c3d_init_replicas
+ *   start           0 (default) random coil, 1 extended strand (chromosome3D.pl:2413-2416)
  *   use_graph       != 0: per-step path replays hipGraphs (default 1)
  *   replica_groups  1..4 stream groups of the per-step path (default 2);  graph_chunk, rows_per_wave,
- *   stage_dma       tuning and test knobs of the per-step kernel */
+ *   stage_dma       tuning and test knobs of the per-step kernel
+ *   event_timing    1 (default) / 0: HIP-event pair around c3d_run / c3d_run_steps (feeds c3d_last_timing)
+ *   kernel_timing   1: start/stop events attached to every multi-step launch (stat "last_kernel_us") */
 int c3d_set_option(c3d_ctx* ctx, const char* key, double value);
 
 /* --- replicas ----------------------------------------------------------------------- */

@@ -1,7 +1,7 @@
 // xcd_handoff.hip — price of the per-step all-gather between the workgroups that own one replica when those
 // workgroups are FEW and LARGE (P workgroups of 1024 or 512 threads, one per CU) and, optionally, all on ONE XCD.
 //
-// Geometry of the candidate resident kernel: 256 workgroups, one per CU.  A workgroup reads HW_REG_XCC_ID, takes a
+// Geometry of the cluster kernel (c3d_cluster.hip): 256 workgroups, one per CU.  A workgroup reads HW_REG_XCC_ID, takes a
 // slot from that XCD's counter and becomes part `slot % P` of cluster (replica) `slot / P` of that XCD, so every
 // cluster lives inside one XCD whatever the dispatcher did (placement = 1).  placement = 0 is the naive
 // blockIdx -> (cluster, part) map that spreads a cluster over the XCDs.
