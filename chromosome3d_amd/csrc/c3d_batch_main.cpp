@@ -8,7 +8,7 @@
 //   assess_dgsa (:106, :769-829)                              c3d_rank, c3d_assess, c3d_write_pdb, c3d_shape_pdb, top 5 renamed
 // Matrices go to GPUs by longest-processing-time-first on N^2 (the restraint count), largest first on every GPU.
 //
-//   c3d_batch <dir with *_matrix.txt | matrix files...> --out <root> [--devices <all>] [-m 20] [-k 11] [-a 0.5]
+//   c3d_batch <dir with *_matrix.txt | matrix files...> --out <root> [--devices <all>] [--lanes 3] [-m 20] [-k 11] [-a 0.5]
 //             [--seed 82364] [--min-steps 3000] [--gtol 1e-2] [--pattern _500kb_]
 // Output: <root>/<chromosome>/ with the files a reference run leaves (<ID>.dist, .rr, contact.tbl, model_info.log,
 // <ID>_model1..5.pdb, <ID>_<k>.pdb) and <root>/<chromosome>.log with the satisfaction table; one summary line per matrix.
@@ -51,7 +51,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
         if ((call) != C3D_OK) { job.summary = std::string(#call) + ": " + c3d_last_error(); return false; } \
     } while (0)
 
-bool solve_one(c3d_ctx* ctx, const Options& o, Job& job) {
+bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     const double t0 = now_s();
     const std::string dir = o.out + "/" + job.chrom;
     mkdir(dir.c_str(), 0755);
@@ -79,7 +79,10 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job) {
     c3d_default_fire(&fire);
     TRY(c3d_set_schedule(ctx, stages.data(), (int)stages.size(), &fire, (float)o.gtol, 250));
     TRY(c3d_init_replicas(ctx, o.models, o.seed, 0));
-    TRY(c3d_run(ctx));
+    {   // one anneal at a time per GPU: the multi-step kernel wants every CU; the host phases of the other lane run meanwhile
+        std::lock_guard<std::mutex> lk(gpu);
+        TRY(c3d_run(ctx));
+    }
     double ms = 0;
     long steps = 0, launches = 0;
     c3d_last_timing(ctx, &ms, &steps, &launches);
@@ -169,7 +172,7 @@ int main(int argc, char** argv) {
     Options o;
     std::vector<std::string> inputs;
     std::string pattern;
-    int devices = -1;
+    int devices = -1, lanes = 3;
     for (int a = 1; a < argc; ++a) {
         const std::string s = argv[a];
         auto next = [&](const char* what) -> const char* {
@@ -178,6 +181,7 @@ int main(int argc, char** argv) {
         };
         if (s == "--out" || s == "-o") o.out = next("--out");
         else if (s == "--devices") devices = atoi(next("--devices"));
+        else if (s == "--lanes") lanes = std::max(1, std::min(4, atoi(next("--lanes"))));
         else if (s == "-m") o.models = atoi(next("-m"));
         else if (s == "-k") o.K = atof(next("-k"));
         else if (s == "-a") o.alpha = atof(next("-a"));
@@ -185,7 +189,7 @@ int main(int argc, char** argv) {
         else if (s == "--min-steps") o.min_steps = atoi(next("--min-steps"));
         else if (s == "--gtol") o.gtol = atof(next("--gtol"));
         else if (s == "--pattern") pattern = next("--pattern");
-        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text]\n"); return 0; }
+        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text]\n"); return 0; }
         else inputs.push_back(s);
     }
     if (o.out.empty() || inputs.empty() || o.models < 1) { fprintf(stderr, "c3d_batch: need input matrices and --out <root> (see --help)\n"); return 2; }
@@ -210,19 +214,27 @@ int main(int argc, char** argv) {
     }
     const double t0 = now_s();
     std::atomic<int> failed{0};
+    // per GPU: `lanes` host threads, each with its own context, take that GPU's jobs in LPT order; while one lane anneals
+    // (the GPU phase, serialised per GPU) the other parses, writes the front-half files, scores and writes models
     std::vector<std::thread> workers;
+    std::vector<std::mutex> gpu_mu(devices);
+    std::vector<std::atomic<size_t>> next_job(devices);
+    for (int g = 0; g < devices; ++g) next_job[g] = 0;
     for (int g = 0; g < devices; ++g)
+      for (int lane = 0; lane < lanes; ++lane)
         workers.emplace_back([&, g]() {
             c3d_ctx* ctx = nullptr;
             if (c3d_create(g, &ctx) != C3D_OK) {
                 std::lock_guard<std::mutex> lk(g_print);
                 fprintf(stderr, "c3d_batch: GPU %d: %s\n", g, c3d_last_error());
-                failed += (int)mine[g].size();
+                for (;;) { const size_t at = next_job[g]++; if (at >= mine[g].size()) break; ++failed; }
                 return;
             }
-            for (size_t k : mine[g]) {
-                Job& job = jobs[k];
-                job.ok = solve_one(ctx, o, job);
+            for (;;) {
+                const size_t at = next_job[g]++;
+                if (at >= mine[g].size()) break;
+                Job& job = jobs[mine[g][at]];
+                job.ok = solve_one(ctx, o, job, gpu_mu[g]);
                 std::lock_guard<std::mutex> lk(g_print);
                 if (job.ok) printf("%s\n", job.summary.c_str());
                 else { printf("FAILED: %s (%s)\n", job.chrom.c_str(), job.summary.c_str()); ++failed; }
@@ -231,7 +243,7 @@ int main(int argc, char** argv) {
             c3d_destroy(ctx);
         });
     for (std::thread& w : workers) w.join();
-    printf("c3d_batch: %zu matrices x %d models on %d GPU(s) in %.2f s, %d failed; models under %s/<chromosome>/<ID>_model1..5.pdb\n", jobs.size(),
-           o.models, devices, now_s() - t0, failed.load(), o.out.c_str());
+    printf("c3d_batch: %zu matrices x %d models on %d GPU(s), %d lane(s) each, in %.2f s, %d failed; models under %s/<chromosome>/<ID>_model1..5.pdb\n", jobs.size(),
+           o.models, devices, lanes, now_s() - t0, failed.load(), o.out.c_str());
     return failed.load() ? 1 : 0;
 }

@@ -159,3 +159,27 @@ def test_perl_driver_fails_loudly_without_gpu(built, tmp_path):
         assert (od / "iam.failed").exists()
         assert "no HIP device" in (out.stderr + out.stdout + open(od / "job.log").read() if (od / "job.log").exists() else out.stderr + out.stdout)
         assert not list(od.glob("*_model*.pdb"))
+
+
+@pytest.mark.gpu
+def test_batch_executor_lanes_do_not_change_results(built, tmp_path):
+    """c3d_batch (test.sh:4-12 in one process): two matrices, once with one and once with two host lanes per GPU — same ranked
+    models byte for byte, the reference's per-chromosome files present."""
+    exe = os.path.join(LIBDIR, "c3d_batch")
+    ind = os.path.join(GOLD, "inputs")
+    outs = []
+    for lanes in (1, 2):
+        od = tmp_path / f"b{lanes}"
+        p = subprocess.run([exe, os.path.join(ind, "chr21_1mb_matrix.txt"), os.path.join(ind, "chr22_1mb_matrix.txt"), "--out", str(od), "--lanes", str(lanes),
+                            "-m", "6"], capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "2 matrices x 6 models" in p.stdout and "0 failed" in p.stdout
+        outs.append(od)
+    for chrom in ("chr21_1mb", "chr22_1mb"):
+        cid = chrom + "_matrix"
+        for f in (f"{cid}.dist", f"{cid}.rr", "contact.tbl", f"{cid}.fasta", "model_info.log"):
+            assert (outs[0] / chrom / f).exists(), f
+        for k in range(1, 6):
+            a = open(outs[0] / chrom / f"{cid}_model{k}.pdb").read()
+            assert a == open(outs[1] / chrom / f"{cid}_model{k}.pdb").read()
+            assert a.count("ATOM") == (37 if chrom == "chr21_1mb" else 35) and a.rstrip().endswith("END")
