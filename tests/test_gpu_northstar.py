@@ -20,11 +20,10 @@ pytestmark = pytest.mark.gpu
 ALL = os.path.join(GOLD, "all45")
 TOL = 0.01
 # |delta| > 0.008 with the shipped model (profiles/r02_parity_sweep_all45.md); sign and size per chromosome.
-# chr22_1mb, chr13_1mb, chr21_500kb (acrocentric: beads next to the unmappable p-arm carry dozens of 40-96 A targets that
-# the chain cannot reach; before the lower-side switch of the NOE term they were off by -0.05),
-# chr16/19/20_1mb, chr19_500kb, chr1_1mb, chr17_1mb: ours above / below the one bundled model by 0.009-0.02.
-EDGE = {"chr22_1mb", "chr13_1mb", "chr21_500kb", "chr16_1mb", "chr19_1mb", "chr19_500kb", "chr20_1mb", "chr1_1mb", "chr17_1mb",
-        "chr1_500kb", "chr21_1mb"}
+# The seven outside +-0.01, with their causes: chr22_1mb, chr13_1mb, chr21_500kb are acrocentric (beads next
+# to the unmappable p-arm carry dozens of 40-96 A targets the chain cannot reach: -0.05 before the lower-side switch of the NOE
+# term, -0.014 .. -0.021 now); chr16/19/20_1mb and chr19_500kb: ours ABOVE the one bundled model by 0.011-0.020 (N = 57-113).
+EDGE = {"chr22_1mb", "chr13_1mb", "chr21_500kb", "chr16_1mb", "chr19_1mb", "chr19_500kb", "chr20_1mb"}
 EDGE_TOL = 0.025
 
 
@@ -79,8 +78,25 @@ def test_all_45_bundled_matrices(solver):
     a = np.abs(np.array(list(d.values())))
     bad = {c: round(float(v), 4) for c, v in d.items() if abs(v) > (EDGE_TOL if c in EDGE else TOL)}
     assert not bad, bad
-    assert (a <= 0.01).sum() >= 36 and (a <= 0.02).sum() >= 43 and a.max() <= 0.03 and a.mean() <= 0.0075, \
+    assert (a <= 0.01).sum() >= 38 and (a <= 0.02).sum() >= 44 and a.max() <= 0.025 and a.mean() <= 0.0065, \
         ((a <= 0.01).sum(), (a <= 0.02).sum(), a.max(), a.mean())
+
+
+def test_k1_bit_exact_on_all_45(solver):
+    """IF -> target distances (tenths of an Angstrom) on the GPU against the CPU restatement of chromosome3D.pl:110-162 for every
+    bundled matrix, and the restraint counts of BASELINE.md."""
+    from chromosome3d_amd import default_model, pipeline
+    from oracle import oracle as O
+    solver.set_model(default_model())
+    total = total_500kb = 0
+    for cid in CIDS:
+        IF = _load(cid)
+        d10 = pipeline.IF2dist_new(solver, IF)
+        assert np.array_equal(d10, O.if_to_dist10(IF)), cid
+        total += solver.num_restraints
+        total_500kb += solver.num_restraints if cid.endswith("_500kb") else 0
+    # restrained pairs (|i-j| >= 5, IF > 0): SURVEY 8d gives 717 360 for the 22 matrices at 500 kb
+    assert total_500kb == 717360 and total == 920419, (total_500kb, total)
 
 
 def test_config4_same_models_whatever_the_rank_count(tmp_path):
