@@ -395,7 +395,7 @@ def main():
             "spearman_reference_model": 0.8722,
             "e_noe_best": round(float(allrec[order[0], 1]), 1),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg runs on rank 0 of the one-GPU run only
             v, sample, all_cores = cpu_baseline(IF, d10, model, fire, stages)
             out["cpu_baseline"] = {"value": round(v, 1), "unit": "replica-steps/s", "cores": 1, "kind": "port",
                                    "sample": sample, "all_cores": all_cores,
