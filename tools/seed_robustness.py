@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""How much of the parity table is the seed?  The all-45 sweep for several seeds: per seed the counts within +-0.01 / 0.02 / 0.03, and
+per chromosome mean and spread of dSpearman (best-ranked replica of 20 against the bundled model).
+    python tools/seed_robustness.py [seeds=82364,1,2,3,4,5,6,7]"""
+import glob, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from chromosome3d_amd import Solver, default_model, default_schedule, default_fire, pipeline
+
+ALL = os.path.join(ROOT, "tests", "golden", "all45")
+seeds = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "82364,1,2,3,4,5,6,7").split(",")]
+
+
+def load(cid):
+    z = np.load(f"{ALL}/{cid}_upper.npz"); n = int(z["n"]); m = np.zeros((n, n)); iu = np.triu_indices(n)
+    m[iu] = z["upper"]; m.T[iu] = z["upper"]; return m
+
+
+def load_pdb(p):
+    return np.array([[float(l[30:38]), float(l[38:46]), float(l[46:54])] for l in open(p) if l.startswith("ATOM")], dtype=np.float32)
+
+
+def key(c):
+    a, b = re.match(r"chr(\d+)_(\w+)", c).groups(); return (b, int(a))
+
+
+s = Solver(0)
+cids = sorted({os.path.basename(p)[:-len("_upper.npz")] for p in glob.glob(f"{ALL}/*_upper.npz")}, key=key)
+D = np.zeros((len(cids), len(seeds)))
+for ci, cid in enumerate(cids):
+    IF = load(cid)
+    ref = -pipeline.spearman_IF_pdb(IF, load_pdb(glob.glob(f"{ALL}/{cid}_rank*_a11.pdb")[0]))
+    s.set_model(default_model())
+    pipeline.IF2dist_new(s, IF)
+    s.set_schedule(default_schedule(3000), default_fire(), 0.0, 250)
+    for si, seed in enumerate(seeds):
+        s.init_replicas(20, seed, 0)
+        s.run()
+        rho = -pipeline.spearman_IF_models(IF, s.coords())
+        best = int(np.argsort(s.energies()[:, 0].astype(np.int64), kind="stable")[0])
+        D[ci, si] = rho[best] - ref
+print("| seed | within 0.01 | within 0.02 | within 0.03 | mean abs | max abs | bias |")
+print("|---|---|---|---|---|---|---|")
+for si, seed in enumerate(seeds):
+    a = np.abs(D[:, si])
+    print(f"| {seed} | {(a <= 0.01).sum()} | {(a <= 0.02).sum()} | {(a <= 0.03).sum()} | {a.mean():.4f} | {a.max():.4f} | {D[:, si].mean():+.4f} |")
+print()
+print("| chromosome | mean d | sd over seeds | min | max | seeds within 0.01 |")
+print("|---|---|---|---|---|---|")
+for ci, cid in enumerate(cids):
+    d = D[ci]
+    print(f"| {cid} | {d.mean():+.4f} | {d.std():.4f} | {d.min():+.4f} | {d.max():+.4f} | {(np.abs(d) <= 0.01).sum()}/{len(seeds)} |")
+m = np.abs(D.mean(1))
+print(f"\nseed-averaged d: within 0.01: {(m <= 0.01).sum()}, within 0.02: {(m <= 0.02).sum()}; typical spread over seeds (median sd) {np.median(D.std(1)):.4f}")
