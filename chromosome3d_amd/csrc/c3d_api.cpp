@@ -133,7 +133,10 @@ struct c3d_ctx {
     int resident_fallbacks = 0;            // resident launches abandoned for the per-step path (see run_resident)
     int resident_skip = 0;                 // ranges left to run step by step before a multi-step launch is tried again
     int resident_backoff = 0;              // doubles with every abandoned launch, back to 0 after a good one
-    int num_cus = 0;
+    int num_cus = 0, num_xcc = 0;
+    int cluster_geom = 0;                  // measurement knob: 100 CW + 10 RPW + helpers forces that cluster geometry (0 = planner's choice)
+    bool inject_incomplete = false;        // test hook: the next cluster launch expects one workgroup more than will ever report
+    int cluster_incomplete = 0;            // cluster launches that ended without the completion mark (and were re-run step by step)
 
     // cluster kernel state (c3d_cluster.hip): the run-length coded program on the device, op -> (run, offset),
     // hand-off records, per-launch slot counters, the host-mapped word a workgroup that gives up writes
@@ -143,7 +146,8 @@ struct c3d_ctx {
     void* d_crec = nullptr;
     size_t crec_bytes = 0;
     static constexpr unsigned kClaimSets = 4096;
-    unsigned* d_claim = nullptr;           // [kClaimSets][8]
+    static constexpr unsigned kClaimWords = 16;   // per launch: [0..7] slot counters of the XCDs, [8] completion counter
+    unsigned* d_claim = nullptr;           // [kClaimSets][kClaimWords]
     unsigned cl_seq = 0;
     c3d::StepRun* d_prog = nullptr;
     size_t prog_cap = 0;
@@ -339,8 +343,12 @@ bool cluster_ok(c3d_ctx* c) {
 // parity p^1 only in its last step, so its inputs are intact whatever happened: if a workgroup gave up waiting (its
 // replica's workgroups were not all resident, e.g. another process fills the GPU) the caller runs the same ops on
 // the per-step path; the next `resident_backoff` ranges go there too before a multi-step launch is tried again.
-bool launch_was_abandoned(c3d_ctx* c) {
-    if (!*c->h_tmo) { c->resident_backoff = 0; return false; }
+bool launch_was_abandoned(c3d_ctx* c, unsigned done_mark) {
+    // complete = the last of the launch's replicas x parts workgroups wrote the mark (c3d_cluster.hip); a launch that
+    // neither timed out nor completed left some (replica, part) unclaimed: same treatment, counted separately
+    const bool complete = c->h_tmo[1] == done_mark;
+    if (!*c->h_tmo && complete) { c->resident_backoff = 0; return false; }
+    if (!*c->h_tmo) ++c->cluster_incomplete;
     *c->h_tmo = 0;
     c->resident_backoff = std::min(4096, std::max(4, 2 * c->resident_backoff));
     c->resident_skip = c->resident_backoff;
@@ -370,16 +378,18 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     const unsigned seq = c->cl_seq % c3d_ctx::kClaimSets;
     if (seq == 0) {
         HIP_TRY(hipMemsetAsync(c->d_crec, 0, c->crec_bytes, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_claim, 0, sizeof(unsigned) * 8 * c3d_ctx::kClaimSets, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_claim, 0, sizeof(unsigned) * c3d_ctx::kClaimWords * c3d_ctx::kClaimSets, c->stream));
     }
     ++c->cl_seq;
     if (c->inject_timeout) { *c->h_tmo = 1; c->inject_timeout = false; }
+    c->h_tmo[1] = 0;
     const c3d::DevModel m = dev_model(c);
     c3d::ClusterPlan pl = c->cl_plan;
+    if (c->inject_incomplete) { ++pl.expected; c->inject_incomplete = false; }
     if (c->kernel_timing) { pl.t0 = c->kev0; pl.t1 = c->kev1; }
     hipError_t e = c3d::launch_cluster(m, dev_fire(c), pl, c->d_io + c->parity, c->buf.tgt, c->d_crec, c->d_prog,
                                        c->op_run[c->pc], c->op_skip[c->pc], (int)nops, seq << 20, c->h_tmo_dev,
-                                       c->d_claim + 8 * seq, c->stream);
+                                       c->d_claim + c3d_ctx::kClaimWords * seq, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("cluster launch: ") + hipGetErrorString(e));
     if (c->event_timing) HIP_TRY(hipEventRecord(c->ev1, c->stream));    // closes the timed range unless more work follows (end_timing)
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -390,7 +400,7 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
         HIP_TRY(hipEventElapsedTime(&kms, c->kev0, c->kev1));
         c->last_kernel_ms += kms;
     }
-    if (launch_was_abandoned(c)) { *ran = false; c->ev1_recorded = false; return C3D_OK; }
+    if (launch_was_abandoned(c, (seq << 20) | 1u)) { *ran = false; c->ev1_recorded = false; return C3D_OK; }
     *ran = true;
     c->last_path = 2;
     account_ops(c, nops);
@@ -619,6 +629,7 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     c3d_ctx* c = new c3d_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
+    if (hipDeviceGetAttribute(&c->num_xcc, hipDeviceAttributeNumberOfXccs, device) != hipSuccess) c->num_xcc = 0;   // unknown: no cluster kernel
     c3d_default_model(&c->model);
     c3d_default_fire(&c->fire);
     c->stages.resize(c3d_default_schedule(nullptr, 0, 3000));
@@ -636,7 +647,8 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     if (ok) {
         *c->h_tmo = 0;
         ok = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_tmo_dev), c->h_tmo, 0) == hipSuccess &&
-             hipMalloc(&c->d_claim, sizeof(unsigned) * 8 * c3d_ctx::kClaimSets) == hipSuccess;
+             hipMalloc(&c->d_claim, sizeof(unsigned) * c3d_ctx::kClaimWords * c3d_ctx::kClaimSets) == hipSuccess;
+        c->h_tmo[1] = 0;
     }
     if (!ok) {
         c3d_destroy(c);
@@ -730,6 +742,14 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
     }
     if (!strcmp(key, "cluster")) { c->cluster = value < 0 ? -1 : (value != 0); return C3D_OK; }
     if (!strcmp(key, "resident_inject_timeout")) { c->inject_timeout = value != 0; return C3D_OK; }   // test hook
+    if (!strcmp(key, "cluster_inject_incomplete")) { c->inject_incomplete = value != 0; return C3D_OK; }   // test hook
+    if (!strcmp(key, "cluster_num_xcc")) { c->num_xcc = (int)value; free_replica_buffers(c); return C3D_OK; }   // test hook: pretend a partitioned device
+    if (!strcmp(key, "cluster_geometry")) {  // measurement knob: 100 CW + 10 RPW + helpers (0 = planner); before c3d_init_replicas
+        if (value < 0 || value > 1699) return fail(C3D_ERR_INVALID, "cluster_geometry = 100 compute waves + 10 rows per wave + helper waves");
+        c->cluster_geom = (int)value;
+        free_replica_buffers(c);
+        return C3D_OK;
+    }
     if (!strcmp(key, "resident_min_ops")) { c->resident_min_ops = value < 1 ? 1 : (int)value; return C3D_OK; }
     if (!strcmp(key, "stage_dma")) { c->stage_dma = value != 0; drop_graphs(c); return C3D_OK; }
     if (!strcmp(key, "graph_chunk")) {
@@ -888,7 +908,7 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 HIP_TRY(hipMalloc(&c->d_sym_scratch, sizeof(float) * c3d::sym_scratch_floats(m)));
             }
-            c->cl_ok = c3d::cluster_plan(m, c->num_cus, &c->cl_plan);
+            c->cl_ok = c3d::cluster_plan(m, c->num_cus, c->num_xcc, c->cluster_geom, &c->cl_plan);
             if (c->cl_ok) {
                 c->cl_plan.device = c->device;
                 c->crec_bytes = c3d::cluster_record_bytes(m, c->cl_plan);
@@ -1141,6 +1161,8 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     else if (!strcmp(key, "resident_launches")) *value = (double)c->resident_launches;
     else if (!strcmp(key, "cluster_launches")) *value = (double)c->cluster_launches;
     else if (!strcmp(key, "resident_fallbacks")) *value = (double)c->resident_fallbacks;
+    else if (!strcmp(key, "cluster_incomplete")) *value = (double)c->cluster_incomplete;
+    else if (!strcmp(key, "num_xcc")) *value = (double)c->num_xcc;
     else if (!strcmp(key, "rms_force")) {
         // max over the replicas of the RMS force component at the last minimiser evaluation (what c3d_run compares with
         // gtol); meaningful after a FIRE step only

@@ -71,7 +71,9 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
                              tbl.c_str(), &R));
     {   // <ID>.fasta (:92-98): one residue per bead, every bead MET as in the bundled output_models
         FILE* fa = fopen((dir + "/" + job.id + ".fasta").c_str(), "w");
-        if (fa) { fprintf(fa, ">%s\n%s\n", job.id.c_str(), std::string((size_t)n, 'M').c_str()); fclose(fa); }
+        if (!fa) { job.summary = "cannot write " + job.id + ".fasta"; return false; }
+        fprintf(fa, ">%s\n%s\n", job.id.c_str(), std::string((size_t)n, 'M').c_str());
+        if (fclose(fa) != 0) { job.summary = "cannot write " + job.id + ".fasta"; return false; }
     }
     std::vector<c3d_stage> stages(c3d_default_schedule(nullptr, 0, o.min_steps));
     c3d_default_schedule(stages.data(), (int)stages.size(), o.min_steps);
@@ -79,7 +81,10 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     c3d_default_fire(&fire);
     TRY(c3d_set_schedule(ctx, stages.data(), (int)stages.size(), &fire, (float)o.gtol, 250));
     TRY(c3d_init_replicas(ctx, o.models, o.seed, 0));
-    {   // one anneal at a time per GPU: the multi-step kernel wants every CU; the host phases of the other lane run meanwhile
+    {   // one anneal at a time per GPU: the multi-step kernel wants every CU; the host phases of the other lanes run meanwhile.
+        // Their short device phases (K1: two kernels of ~20 us, coordinate copies) are NOT serialised: a cluster launch whose
+        // workgroups find a CU busy with one of them becomes resident as soon as it drains, microseconds later, far inside
+        // the 0.3 s after which a launch gives up (c3d_cluster.hip); the fallback counter stays 0 in profiles/r02_config4_*.
         std::lock_guard<std::mutex> lk(gpu);
         TRY(c3d_run(ctx));
     }
@@ -100,7 +105,11 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     TRY(c3d_read_tbl(tbl.c_str(), &pi, &pj, &pt, &Rt));
     std::vector<int32_t> ri(pi, pi + Rt), rj(pj, pj + Rt), rt(pt, pt + Rt);
     c3d_free(pi); c3d_free(pj); c3d_free(pt);
-    FILE* lg = fopen((o.out + "/" + job.chrom + ".log").c_str(), "w");
+    struct FileCloser {                              // closes the log on every exit path (the TRY macros return early)
+        FILE* f;
+        ~FileCloser() { if (f) fclose(f); }
+    } lgc{fopen((o.out + "/" + job.chrom + ".log").c_str(), "w")};
+    FILE* const lg = lgc.f;
     if (!lg) { job.summary = "cannot write the log"; return false; }
     fprintf(lg, "L          : %d\nRestraints : %d lines in tbl file\n\nNOE_SATISFIED(+-0.5A)  SUM_OF_DEVIATIONS>= 0.2  PDB\n", n, R);
     std::vector<std::string> names(M);
@@ -127,9 +136,10 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
         char dst[96];
         snprintf(dst, sizeof dst, "%s_model%d.pdb", job.id.c_str(), k + 1);
         fprintf(lg, "model%d.pdb <= %s\n", k + 1, names[rank[k]].c_str());
-        if (rename(names[rank[k]].c_str(), (dir + "/" + dst).c_str()) != 0) { fclose(lg); job.summary = "rename failed"; return false; }
+        if (rename(names[rank[k]].c_str(), (dir + "/" + dst).c_str()) != 0) { job.summary = "rename failed"; return false; }
     }
-    fclose(lg);
+    lgc.f = nullptr;
+    if (fclose(lg) != 0) { job.summary = "cannot write the log"; return false; }
     char buf[320];
     snprintf(buf, sizeof buf, "%-14s N=%4d R=%6d  %2d models  best: replica %2d  E_noe %12.1f  Spearman(IF,1/d) %.4f  anneal %6.1f ms (%ld steps)  "
                               "end-to-end %.2f s  GPU %d",
@@ -219,17 +229,18 @@ int main(int argc, char** argv) {
     std::vector<std::thread> workers;
     std::vector<std::mutex> gpu_mu(devices);
     std::vector<std::atomic<size_t>> next_job(devices);
-    for (int g = 0; g < devices; ++g) next_job[g] = 0;
+    std::vector<std::atomic<int>> lanes_up(devices);
+    for (int g = 0; g < devices; ++g) { next_job[g] = 0; lanes_up[g] = 0; }
     for (int g = 0; g < devices; ++g)
       for (int lane = 0; lane < lanes; ++lane)
         workers.emplace_back([&, g]() {
             c3d_ctx* ctx = nullptr;
-            if (c3d_create(g, &ctx) != C3D_OK) {
+            if (c3d_create(g, &ctx) != C3D_OK) {     // this lane only: the GPU's other lanes take its jobs (see below if none came up)
                 std::lock_guard<std::mutex> lk(g_print);
                 fprintf(stderr, "c3d_batch: GPU %d: %s\n", g, c3d_last_error());
-                for (;;) { const size_t at = next_job[g]++; if (at >= mine[g].size()) break; ++failed; }
                 return;
             }
+            ++lanes_up[g];
             for (;;) {
                 const size_t at = next_job[g]++;
                 if (at >= mine[g].size()) break;
@@ -243,6 +254,13 @@ int main(int argc, char** argv) {
             c3d_destroy(ctx);
         });
     for (std::thread& w : workers) w.join();
+    for (int g = 0; g < devices; ++g) {              // a GPU on which no lane got a context: its jobs were never taken
+        if (lanes_up[g] > 0) continue;
+        for (size_t at = 0; at < mine[g].size(); ++at) {
+            printf("FAILED: %s (no context on GPU %d)\n", jobs[mine[g][at]].chrom.c_str(), g);
+            ++failed;
+        }
+    }
     printf("c3d_batch: %zu matrices x %d models on %d GPU(s), %d lane(s) each, in %.2f s, %d failed; models under %s/<chromosome>/<ID>_model1..5.pdb\n", jobs.size(),
            o.models, devices, lanes, now_s() - t0, failed.load(), o.out.c_str());
     return failed.load() ? 1 : 0;

@@ -28,6 +28,7 @@
 // host re-runs the range step by step (the launch only writes its outputs in its last step).
 // Deck: chromosome3D.pl:1646-1700 (hot MD), :1729-1782 (cooling), :1790-1803 (minimisation).
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const AnnealIO* __restrict__ io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
     const StepRun* __restrict__ runs, const int run0, const int skip0, const int nsteps, const unsigned tag_base,
     volatile unsigned* __restrict__ timeout, unsigned* __restrict__ claim, const int P, const int CW, const int NH,
-    const DevModel m, const DevFire fp) {
+    const unsigned expected, const DevModel m, const DevFire fp) {
     constexpr int NPAD = 256 * NB;
     constexpr int MAXT = NPAD / 8;
     constexpr int KUMAX = NB > 2 ? 3 : 2;         // gather loads per thread: P * 2 RW <= threads * KUMAX
@@ -245,6 +246,11 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 const int tl = (wg_row0 + lane) >> 3;
                 if ((lane & 7) == 0 && lane < RW && tl < m.ntiles) reinterpret_cast<float4*>(io->pout)[(size_t)rep * m.ntiles + tl] = t;
                 if (lane == 0 && part == 0) io->sout[rep] = st;
+                // completion: claim[8] counts the workgroups that reached their last step; the one that completes the launch's
+                // `expected` = replicas x parts says so in the host-mapped word next to *timeout.  A launch in which some
+                // (replica, part) was never claimed (fewer workgroups on an XCD than the plan assumes) or abandoned never
+                // writes it, and the host re-runs the range on the per-step path instead of accepting stale state.
+                if (lane == 0 && atomicAdd(&claim[8], 1u) + 1u == expected) timeout[1] = tag_base | 1u;
             } else if (solo) {
                 // one workgroup owns the replica: new positions and tile sums go straight back into LDS
                 if (lane < RW && hrow < NPAD) { xs[hrow] = xn; ys[hrow] = yn; zs[hrow] = zn; }
@@ -312,8 +318,10 @@ hipError_t read_cluster_stamps(unsigned long long* out) { return hipMemcpyFromSy
 // Among the geometries that fit, the cheapest by an instruction-count model of one step (VALU issue is the limiter):
 //   per SIMD: ceil(CW / 4) compute waves x (RPW rows x NB blocks x 4 columns x 15 + 60) wave-instructions,
 //   + H0's serial tail (~200) + the hand-off (~570 instruction-times = 0.8 us) unless P == 1.
-bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan) {
-    if (m.npad > 1024 || num_cus < 8 || num_cus % 8) return false;
+bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, ClusterPlan* plan) {
+    // the placement arithmetic (replica r on XCD r % 8, XCC_ID & 7) is written for the 8 XCDs of an unpartitioned MI355X:
+    // on a partitioned or CU-masked device the cluster kernel is not used at all
+    if (m.npad > 1024 || num_xcc != 8 || num_cus < 8 || num_cus % 8) return false;
     const int cus_per_xcd = num_cus / 8;
     const int per_xcd = (m.nrep_g + 7) / 8;
     const int nb = m.npad / 256;
@@ -324,9 +332,8 @@ bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan) {
     //  another's pair loop — measured slower at every size: twice the records per replica, twice the helper work per CU)
     double best = 1e30;
     bool found = false;
-    const char* force = getenv("C3D_CLUSTER_GEOM");   // diagnostic: "CWxRPWxHELPERS", e.g. 12x4x4
-    int fcw = 0, frpw = 0, fnh = 0;
-    if (force && sscanf(force, "%dx%dx%d", &fcw, &frpw, &fnh) != 3) fcw = frpw = fnh = 0;
+    // measurement knob (c3d_set_option "cluster_geometry" = 100 CW + 10 RPW + helpers, e.g. 1244): only that geometry
+    const int fcw = forced_geom / 100, frpw = forced_geom / 10 % 10, fnh = forced_geom % 10;
     for (const auto& g : geoms) {
         const int cw = g[0], rpw = g[1], nh = g[2], wpc = g[3], rw = cw * rpw;
         if (fcw && (cw != fcw || rpw != frpw || nh != fnh)) continue;
@@ -351,6 +358,7 @@ bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan) {
             best = cost; found = true;
             plan->rpw = rpw; plan->cw = cw; plan->helpers = nh; plan->wgs_per_cu = wpc; plan->parts = P; plan->per_xcd = per_xcd;
             plan->grid = num_cus * wpc; plan->threads = threads; plan->units = 2 * rw; plan->device = 0; plan->lds = lds;
+            plan->expected = (unsigned)(m.nrep_g * P);
         }
     }
     return found;
@@ -362,19 +370,21 @@ template <int POT, int RPW, int NB, bool RS1>
 static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
                              const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                              hipStream_t s) {
-    static bool attr_set[64] = {};                // per device: more dynamic LDS than the 64 KB a launch gets by default
+    // per (instantiation, device): more dynamic LDS than the 64 KB a launch gets by default.  Contexts of several host
+    // threads launch concurrently (c3d_batch): the flag is atomic, setting the attribute twice is harmless
+    static std::atomic<bool> attr_set[64];
     const int dev = pl.device & 63;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, RS1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     if (pl.t0 && pl.t1)
         hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, RS1>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
-                              reinterpret_cast<u32x4*>(rec), runs, run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, m, fp);
+                              reinterpret_cast<u32x4*>(rec), runs, run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, m, fp);
     else
         hipLaunchKernelGGL((k_cluster<POT, RPW, NB, RS1>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
-                           run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, m, fp);
+                           run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, m, fp);
     return hipGetLastError();
 }
 template <int POT>

@@ -98,13 +98,16 @@ AnnealIO anneal_io(const DevBuffers& b, int parity);
 // wgs_per_cu x number of CUs.
 // `runs` is the run-length coded step list of the WHOLE program (uploaded once); the launch starts `skip0` steps into
 // run `run0` and makes `nsteps` steps.  `tag_base` (launch sequence number << 20) keeps the tags of different launches
-// apart, `claim` points at 8 zeroed slot counters that no other launch has used, *timeout = 0.
+// apart, `claim` points at 16 zeroed words that no other launch has used ([0..7] slot counters per XCD, [8] completion
+// counter), timeout[0] = 0 (set by a workgroup that gives up), timeout[1] = 0 (set to tag_base | 1 by the workgroup that
+// completes the launch's pl.expected).
 struct ClusterPlan {
     int rpw, cw, helpers, wgs_per_cu, parts, per_xcd, grid, threads, units, device;
+    unsigned expected = 0;                        // workgroups that must report completion: replicas x parts (the host may raise it: test hook)
     size_t lds;
     hipEvent_t t0 = nullptr, t1 = nullptr;        // when set: the launch stamps them with the kernel's own start and end
 };
-bool cluster_plan(const DevModel& m, int num_cus, ClusterPlan* plan);
+bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, ClusterPlan* plan);
 size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl);
 hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout,

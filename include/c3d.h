@@ -109,6 +109,11 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *   resident        -1 (default) / 0 / 1: run step ranges as ONE multi-step launch of the cluster kernel (c3d_cluster.hip)
  *                   wherever a geometry exists / never / as -1, without the back-off after an abandoned launch
  *   cluster         0: never use the cluster kernel (test knob)
+ *   cluster_geometry  100 x compute waves + 10 x rows per wave + helper waves (e.g. 1244): force that geometry of the cluster
+ *                   kernel instead of the planner's choice (measurement knob; 0 = planner); before c3d_init_replicas
+ *   cluster_num_xcc, cluster_inject_incomplete, resident_inject_timeout   test hooks of the cluster kernel's safety net
+ *                   (a device that does not expose 8 XCDs gets no cluster plan; a launch that ends without its completion
+ *                   mark or with a time-out is re-run on the per-step path)
  *   precision       32 (default) or 64: the fp64 reference kernels (c3d_f64.hip); call before c3d_init_replicas
  *   symmetric       1: symmetric-tile kernels for large N (c3d_sym.hip; opt-in); call before c3d_init_replicas
  *   start           0 (default) random coil, 1 extended strand (chromosome3D.pl:2413-2416)
@@ -148,7 +153,8 @@ int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* lau
 /* Counters of the context since c3d_create, for benchmarks and tests (no reference counterpart: the reference's
  * only instrument is the wall clock around `./job.sh`, chromosome3D.pl:287).  Keys: "graph_captures" (hipGraphs
  * captured + instantiated), "graph_launches", "graphs_cached", "step_launches" (k_step dispatches), "resident_launches",
- * "cluster_launches", "resident_fallbacks" (multi-step launches abandoned for the per-step path), "last_path"
+ * "cluster_launches", "resident_fallbacks" (multi-step launches abandoned for the per-step path), "cluster_incomplete"
+ * (those of them that ended without every (replica, part) workgroup reporting), "num_xcc", "last_path"
  * (0 per-step, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "cluster_compute_waves", "replica_groups",
  * "k1_recomputed" (elements of the last c3d_set_if_matrix that sat within 1e-10 of a "%.1f" rounding tie and were redone
  * on the host in the reference's operation order), "k1_patched" (how many of those changed, since c3d_create),

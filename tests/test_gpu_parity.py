@@ -536,3 +536,33 @@ def test_cluster_launch_that_times_out_falls_back_to_per_step(solver):
     xb, vb, eb, tb = _anneal(solver, "chr21_1mb", 4, 1, inject=True)
     assert tb[2] > 40                           # ran step by step after the abandoned launch
     assert np.array_equal(xa, xb) and np.array_equal(ea, eb)
+
+
+@pytest.mark.parametrize("cid,nrep", [("chr21_1mb", 4), ("chr1_500kb", 3)])
+def test_cluster_launch_without_completion_mark_is_not_accepted(solver, cid, nrep):
+    """A launch in which some (replica, part) never ran — fewer workgroups on an XCD than the plan assumes: a partitioned
+    or CU-masked device, an uneven dispatch — must not hand stale state back as a result.  The kernel counts the workgroups
+    that reach their last step and the last one writes a mark the host checks; here the host expects one workgroup more than
+    exist (test hook), so the mark never comes: the range is re-run step by step and ends in the per-step path's bits.
+    chr21_1mb: one workgroup per replica (P == 1, nobody waits for anybody: the case a time-out cannot catch)."""
+    xa, va, ea, ta = _anneal(solver, cid, nrep, 0)
+    before = solver.stat("cluster_incomplete"), solver.stat("resident_fallbacks")
+    solver.set_option("cluster_inject_incomplete", 1)
+    xb, vb, eb, tb = _anneal(solver, cid, nrep, 1)
+    assert solver.stat("cluster_incomplete") == before[0] + 1 and solver.stat("resident_fallbacks") == before[1] + 1
+    assert tb[2] > 40                           # ran step by step after the rejected launch
+    assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(ea, eb)
+
+
+def test_no_cluster_plan_on_a_device_without_eight_xcds(solver):
+    """The placement arithmetic of the cluster kernel is written for the 8 XCDs of an unpartitioned MI355X; a context that
+    sees any other number (test hook: cluster_num_xcc) plans no cluster launch at all and runs the per-step path."""
+    assert solver.stat("num_xcc") == 8
+    xa, va, ea, ta = _anneal(solver, "chr21_1mb", 4, 0)
+    solver.set_option("cluster_num_xcc", 4)
+    try:
+        xb, vb, eb, tb = _anneal(solver, "chr21_1mb", 4, -1)
+        assert solver.stat("cluster_parts") == 0 and solver.stat("last_path") == 0 and tb[2] > 40
+        assert np.array_equal(xa, xb) and np.array_equal(ea, eb)
+    finally:
+        solver.set_option("cluster_num_xcc", 8)

@@ -97,3 +97,45 @@ def synthetic_if(n, seed=20161015, K=11.0, alpha=0.5, sigma=0.2, radius=None):
     np.fill_diagonal(IF, 0.0)
     np.fill_diagonal(IF, 10.0 * IF.max(axis=1))
     return IF, x - x.mean(0)
+
+
+# ---- structure-level comparison of a solver model with the bundled reference model of the same matrix ----------
+def bundled_rank(path):
+    """`chr1_500kb_rank03_a11.pdb` -> 3: the rank (by the reference's own NOE energy) of the one model the reference ships."""
+    import re
+    m = re.search(r"_rank(\d+)_a(\d+)\.pdb$", os.path.basename(path))
+    return int(m.group(1)) if m else 1
+
+
+def chain_stats(x):
+    """(bond mean, bond sd, |i-j|=2 mean, |i-j|=2 sd, radius of gyration) of one model [N, 3] — the envelope SURVEY 8a/8c names."""
+    x = np.asarray(x, dtype=np.float64)
+    b = np.linalg.norm(x[1:] - x[:-1], axis=1)
+    a = np.linalg.norm(x[2:] - x[:-2], axis=1)
+    rg = float(np.sqrt(((x - x.mean(0)) ** 2).sum(1).mean()))
+    return float(b.mean()), float(b.std()), float(a.mean()), float(a.std()), rg
+
+
+def structure_report(IF, x, e_noe, ref_xyz, ref_rank=1):
+    """Everything the parity table holds for one matrix: x [M, N, 3] our replicas, e_noe [M], ref_xyz [N, 3] the bundled
+    model, ref_rank its rank in the reference's run.  Scoring through the product's pinned host routines
+    (spearman_IF_pdb.pl:42-70 = c3d_spearman_if_dist; output_models/similarity.txt = c3d_model_similarity)."""
+    from chromosome3d_amd import pipeline
+    x = np.asarray(x)
+    M = x.shape[0]
+    rho = -pipeline.spearman_IF_models(IF, x)
+    order = np.argsort(np.asarray(e_noe).astype(np.int64), kind="stable")       # ascending int(E_noe), chromosome3D.pl:796-802
+    best = int(order[0])
+    matched = int(order[min(ref_rank, M) - 1])
+    rho_ref = -pipeline.spearman_IF_pdb(IF, np.asarray(ref_xyz, dtype=np.float32))
+    sim_best = pipeline.model_similarity(x[best], ref_xyz)
+    sim_match = pipeline.model_similarity(x[matched], ref_xyz)
+    # how alike two of OUR replicas are: the scale on which "same structure as the reference's" has to be read
+    sim_own = pipeline.model_similarity(x[best], x[int(order[1])]) if M > 1 else (1.0, 0.0)
+    ours, ref = chain_stats(x[best]), chain_stats(ref_xyz)
+    return dict(rho=rho, order=order, best=best, matched=matched, rho_best=float(rho[best]), rho_matched=float(rho[matched]),
+                rho_mean=float(rho.mean()), rho_ref=float(rho_ref), delta=float(rho[best] - rho_ref),
+                delta_matched=float(rho[matched] - rho_ref),
+                ref_percentile=float((rho < rho_ref).mean()),      # fraction of our replicas below the reference's value
+                sim_best=sim_best, sim_matched=sim_match, sim_own=sim_own, chain=ours, chain_ref=ref,
+                rg_ratio=ours[4] / ref[4])

@@ -1,0 +1,204 @@
+"""Inverse force matching on the reference's 45 bundled models (output_models/*_a11.pdb; committed as tests/golden/all45).
+
+Every bundled model is a local minimum of the energy CNS minimised (deck chromosome3D.pl:1790-1803: 10 x 15000 L-BFGS
+steps), so the total force on every bead vanishes there.  CNS itself cannot run here, but that condition alone pins the SHAPE
+of the restraint potential: write the NOE derivative g(delta) = dE/dd (delta = d - target) as an unknown function, give
+every pseudo-bond (i,i+1) and (i,i+2) its own free tension (they absorb the covalent geometry of the pseudo-protein, which a
+bead model cannot know), add a free piecewise-linear repel h(d) for |i-j| >= 3, and ask which g leaves the smallest
+residual force.  Host only (numpy); no GPU, no oracle in the product.
+
+    python tools/calib/force_match.py shape     # g(delta) recovered point by point, lower side pinned to 2 S delta
+    python tools/calib/force_match.py grid      # residual over (rswitch, asymptote) x (lower side: square / soft)
+    python tools/calib/force_match.py chain     # bond and (i,i+2) tension against distance under the best NOE form
+Committed output: profiles/r03_force_matching.txt.  What it says (both resolutions separately, same answer):
+the upper tail of the soft-square is HALF of what round 2 used (switch at 0.5 A, slope 2 S 0.5 = 10, i.e. CNS
+`rswitch 0.5, asymptote 1.0` rather than `1.0 / 2.0`), the lower side is square up to 7-11 A and saturates beyond,
+pseudo-bond stiffness ~300 kcal/mol/A^2 around 3.95 A, (i,i+2) ~45 around 6.1 A, and the repel term is steeper and
+shorter-ranged (contact ~4.2 A) than round 2's.
+"""
+import glob, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+from tests.util import load_pdb_xyz
+
+ALL = os.path.join(ROOT, "tests", "golden", "all45")
+RGRID = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 10], float)       # repel: hat functions of d, the last one pinned to 0
+KR = len(RGRID)
+S_NOE = 10.0
+
+
+def load(cid):
+    z = np.load(f"{ALL}/{cid}_upper.npz"); n = int(z["n"]); m = np.zeros((n, n)); iu = np.triu_indices(n)
+    m[iu] = z["upper"]; m.T[iu] = z["upper"]; return m
+
+
+def targets(IF, alpha=0.5, K=11.0):
+    """chromosome3D.pl:110-162 in numpy: tenths of an Angstrom as "%.1f" prints them (ties irrelevant at this use)."""
+    P = IF ** alpha
+    with np.errstate(divide="ignore"):
+        D = K / (P / P.mean())
+    return np.where(IF > 0, np.round(D, 1), -1.0)
+
+
+def hat(x, g):
+    x = np.clip(x, g[0], g[-1]); i = np.clip(np.searchsorted(g, x, side="right") - 1, 0, len(g) - 2)
+    w1 = (x - g[i]) / (g[i + 1] - g[i]); return i, 1 - w1, i + 1, w1
+
+
+class Model:
+    pass
+
+
+def prepare(sel=None, free=(1, 2)):
+    out = []
+    cids = sorted({os.path.basename(p)[:-len("_upper.npz")] for p in glob.glob(f"{ALL}/*_upper.npz")})
+    for cid in cids:
+        if sel and not re.search(sel, cid):
+            continue
+        ref = glob.glob(f"{ALL}/{cid}_rank*_a11.pdb")
+        if not ref:
+            continue
+        IF = load(cid); n = len(IF); X = load_pdb_xyz(ref[0])
+        if len(X) != n:
+            continue
+        T = targets(IF)
+        U = X[:, None] - X[None]; D = np.linalg.norm(U, axis=-1); np.fill_diagonal(D, 1); Uh = U / D[..., None]
+        i, j = np.triu_indices(n, 1); sep = j - i
+        m = Model(); m.cid = cid; m.n = n; m.D = D; m.Uh = Uh
+        r = (sep >= 5) & (T[i, j] > 0)
+        m.ii, m.jj = i[r], j[r]; m.dl = D[m.ii, m.jj] - T[m.ii, m.jj]; m.u = Uh[m.ii, m.jj]
+        r = sep >= 3; ii, jj = i[r], j[r]
+        R = np.zeros((3 * n, KR))
+        a0, w0, a1, w1 = hat(D[ii, jj], RGRID)
+        for (a, w) in ((a0, w0), (a1, w1)):
+            f = w[:, None] * Uh[ii, jj]
+            for c in range(3):
+                np.add.at(R, (3 * ii + c, a), f[:, c]); np.add.at(R, (3 * jj + c, a), -f[:, c])
+        cols = []
+        for s in free:
+            for a in range(n - s):
+                c = np.zeros(3 * n); u = Uh[a, a + s]; c[3 * a:3 * a + 3] = u; c[3 * (a + s):3 * (a + s) + 3] = -u; cols.append(c)
+        m.Fr = np.array(cols).T
+        m.Q, _ = np.linalg.qr(m.Fr)
+        m.Rp = (R - m.Q @ (m.Q.T @ R))[:, :KR - 1]
+        out.append(m)
+    return out
+
+
+def noe_force(m, g, project=True):
+    gv = g(m.dl)
+    F = np.zeros((m.n, 3)); f = -(gv[:, None]) * m.u
+    np.add.at(F, m.ii, f); np.add.at(F, m.jj, -f)
+    F = F.ravel()
+    return F - m.Q @ (m.Q.T @ F) if project else F
+
+
+def residual(models, g):
+    Fn = np.concatenate([noe_force(m, g) for m in models])
+    Rp = np.vstack([m.Rp for m in models])
+    h, *_ = np.linalg.lstsq(Rp, -Fn, rcond=None)
+    return np.linalg.norm(Fn + Rp @ h) / np.linalg.norm(Fn), h
+
+
+def soft(rs, c, mrs=None, mc=None, S=S_NOE):
+    """CNS soft-square derivative: 2 S delta for -mrs <= delta <= rs; above: S (c - b / delta^2), b from continuity at rs
+    (c = slope at infinity / S); below -mrs (optional): the mirrored form with (mrs, mc)."""
+    b = (c - 2 * rs) * rs * rs
+
+    def g(dl):
+        out = 2 * S * dl
+        up = dl > rs
+        out[up] = S * (c - b / dl[up] ** 2)
+        if mrs is not None:
+            lo = dl < -mrs
+            mb = (mc - 2 * mrs) * mrs * mrs
+            out[lo] = -S * (mc - mb / dl[lo] ** 2)
+        return out
+    return g
+
+
+def mode_shape():
+    grid = np.array([-60, -40, -30, -25, -20, -16, -13, -11, -9, -7, -5, -4, -3, -2, -1, 0, 1, 2, 3, 4, 5, 7, 9, 12, 16, 20, 30, 40], float)
+    K = len(grid)
+    for sel in (None, "_1mb", "_500kb"):
+        models = prepare(sel)
+        rows = []
+        for m in models:
+            G = np.zeros((3 * m.n, K))
+            a0, w0, a1, w1 = hat(m.dl, grid)
+            for (a, w) in ((a0, w0), (a1, w1)):
+                f = -(w[:, None]) * m.u
+                for c in range(3):
+                    np.add.at(G, (3 * m.ii + c, a), f[:, c]); np.add.at(G, (3 * m.jj + c, a), -f[:, c])
+            rows.append(np.hstack([G - m.Q @ (m.Q.T @ G), m.Rp]))
+        A = np.vstack(rows)
+        pin = [k for k in range(K) if -5 <= grid[k] <= 0]
+        b = -(A[:, pin] * (2 * S_NOE * grid[pin])[None, :]).sum(1)
+        keep = [k for k in range(A.shape[1]) if k not in pin]
+        sol, *_ = np.linalg.lstsq(A[:, keep], b, rcond=None)
+        full = np.zeros(A.shape[1]); full[pin] = 2 * S_NOE * grid[pin]; full[keep] = sol
+        print(f"\n== shape: {len(models)} models ({sel or 'all'}), g pinned to {2 * S_NOE:.0f} delta on [-5, 0]; residual {np.linalg.norm(A @ full) / np.linalg.norm(b):.3f} of the pinned part")
+        print("   delta      g(delta)   pairs-weight     [square well: 20 delta; round 2: +20 beyond 1 A; found: ~+10 beyond 0.5 A]")
+        for k in range(K):
+            print(f"  {grid[k]:6.1f}  {full[k]:10.2f}   {np.linalg.norm(A[:, k]):10.1f}")
+        print("   d          repel h(d), |i-j| >= 3 (tension, > 0 pushes apart)")
+        for k in range(KR - 1):
+            print(f"  {RGRID[k]:6.1f}  {full[K + k]:10.2f}")
+
+
+def mode_grid():
+    models = prepare(None)
+    m1 = [m for m in models if m.cid.endswith("_1mb")]; m5 = [m for m in models if m.cid.endswith("_500kb")]
+    cs = [0.4, 0.6, 0.8, 1.0, 1.2, 1.5, 2.0, 3.0]
+    for label, lower in (("lower side square everywhere", (None, None)), ("lower side clamps at 11 A (round 2)", (11.0, 22.0)), ("lower side clamps at 7 A", (7.0, 14.0))):
+        print(f"\n== grid, {label}: residual |F| / |F_noe| over all 45 models; rows rswitch, columns asymptote slope / S")
+        print("  rs\\c  " + " ".join(f"{c:7.2f}" for c in cs))
+        for rs in (0.25, 0.5, 0.75, 1.0, 1.5, 2.0):
+            print(f"  {rs:4.2f}  " + " ".join(f"{residual(models, soft(rs, c, *lower))[0]:7.4f}" for c in cs))
+    print("\n== clamp on both sides (slope 2 S rswitch above, 2 S mrswitch below: the form the fast kernels evaluate): all | 1 Mb | 500 kb")
+    for rs in (0.4, 0.5, 0.6, 0.7, 0.8, 1.0):
+        for mrs in (5.0, 7.0, 9.0, 11.0, 13.0):
+            g = soft(rs, 2 * rs, mrs, 2 * mrs)
+            print(f"  rswitch {rs:.2f} mrswitch {mrs:4.1f}: " + " ".join(f"{residual(ms, g)[0]:.4f}" for ms in (models, m1, m5)))
+
+
+def mode_chain():
+    g = soft(0.5, 1.0, 7.0, 14.0)
+    for sel in ("_1mb", "_500kb"):
+        models = prepare(sel)
+        _, h = residual(models, g)
+        hh = np.append(h, 0.0)
+        allb, alla = [], []
+        for m in models:
+            F = noe_force(m, g, project=False).reshape(m.n, 3)
+            i, j = np.triu_indices(m.n, 3)
+            f = np.interp(m.D[i, j], RGRID, hh)[:, None] * m.Uh[i, j]
+            np.add.at(F, i, f); np.add.at(F, j, -f)
+            sol, *_ = np.linalg.lstsq(m.Fr, -F.ravel(), rcond=None)
+            nb = m.n - 1
+            allb += [(m.D[a, a + 1], sol[a]) for a in range(nb)]
+            alla += [(m.D[a, a + 2], sol[nb + a]) for a in range(m.n - 2)]
+        b, a = np.array(allb), np.array(alla)
+        print(f"\n== chain ({sel}): repel h on d = 0..8: {np.round(h, 1).tolist()}")
+        for name, arr, bins in (("bond (i,i+1)", b, np.arange(3.0, 6.2, 0.2)), ("(i,i+2)", a, np.arange(0.0, 12.5, 1.0))):
+            print(f"  {name}: tension (> 0 pushes apart) against distance")
+            idx = np.digitize(arr[:, 0], bins)
+            for k in range(1, len(bins)):
+                v = arr[idx == k]
+                if len(v) > 2:
+                    print(f"    d [{bins[k - 1]:4.1f},{bins[k]:4.1f})  n = {len(v):4d}  mean {v[:, 1].mean():9.1f}  median {np.median(v[:, 1]):9.1f}")
+        k, c = np.polyfit(b[:, 0], b[:, 1], 1)
+        print(f"  bond linear fit: k_bond = {-k / 2:.1f}, b0 = {-c / k:.3f}")
+        mk = (a[:, 0] > 3) & (a[:, 0] < 9); k, c = np.polyfit(a[mk, 0], a[mk, 1], 1)
+        print(f"  (i,i+2) linear fit over 3..9 A: k = {-k / 2:.1f}, a0 = {-c / k:.3f}")
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if mode in ("shape", "all"):
+        mode_shape()
+    if mode in ("grid", "all"):
+        mode_grid()
+    if mode in ("chain", "all"):
+        mode_chain()

@@ -1,41 +1,40 @@
-"""All-chromosome parity sweep on the GPU: Spearman(IF, 1/d) of our ranked models vs the bundled
-reference model of every chromosome, plus chain statistics.
+"""All-chromosome parity sweep on the GPU against the reference's bundled models (output_models/*_a11.pdb, the only
+solver evidence the reference holds): per matrix
+  * Spearman(IF, 1/d) of our best-ranked and of our RANK-MATCHED replica (rankNN of the bundled file's name) vs the
+    bundled model's, and where the reference's value falls inside our 20-replica distribution;
+  * structure-level similarity of our model with the bundled one: Spearman of the pairwise distances and the scaled
+    dRMSD, the two numbers of output_models/similarity.txt (c3d_model_similarity); for scale, the same between our two
+    best replicas, and the reference's own 500 kb vs 1 Mb agreement is 0.855-0.967;
+  * the chain envelope: bond mean/sd, |i-j| = 2 mean/sd, radius of gyration ratio.
 
-    python tools/parity_sweep.py [json model overrides] [replicas=20] [subset regex]
-Needs tests/golden/all45 (tools/pack_all_inputs.py; git-ignored data, present on the GPU box through
-the gpurun snapshot).  Prints a markdown table; the committed copy lives in profiles/.
+    python tools/parity_sweep.py ['{json model overrides}'] [replicas=20] [subset regex]
+Extra keys in the overrides: min_steps, quiet, embed, seed, dump (path of an .npz receiving every replica's coordinates).
+Prints a markdown table; the committed copy lives in profiles/.
 """
 import glob, json, os, re, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from chromosome3d_amd import Solver, default_model, default_schedule, default_fire, pipeline
+from tests.util import bundled_rank, load_pdb_xyz, structure_report
 
 ALL = os.path.join(ROOT, "tests", "golden", "all45")
-over = json.loads(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].startswith("{") else {}
-nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-subset = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
-min_steps = int(over.pop("min_steps", 3000))
-quiet = over.pop("quiet", 0)
-embed = over.pop("embed", 0)
-seed = int(over.pop("seed", 82364))
+
 
 def load(cid):
     z = np.load(f"{ALL}/{cid}_upper.npz"); n = int(z["n"]); m = np.zeros((n, n)); iu = np.triu_indices(n)
     m[iu] = z["upper"]; m.T[iu] = z["upper"]; return m
-def load_pdb(p):
-    return np.array([[float(l[30:38]), float(l[38:46]), float(l[46:54])] for l in open(p) if l.startswith("ATOM")])
+
+
 def key(c):
     a, b = re.match(r"chr(\d+)_(\w+)", c).groups(); return (b, int(a))
 
-s = Solver(0)
-cids = sorted({os.path.basename(p)[:-len("_upper.npz")] for p in glob.glob(f"{ALL}/*_upper.npz")}, key=key)
-rows, t_all = [], time.time()
-for cid in cids:
-    if subset and not subset.search(cid): continue
-    IF = load(cid); n = IF.shape[0]
-    ref = glob.glob(f"{ALL}/{cid}_rank*_a11.pdb")
-    Xr = load_pdb(ref[0]) if ref else None
+
+def all_cids():
+    return sorted({os.path.basename(p)[:-len("_upper.npz")] for p in glob.glob(f"{ALL}/*_upper.npz")}, key=key)
+
+
+def solve(s, IF, over, nrep=20, seed=82364, min_steps=3000, embed=0):
     s.set_model(default_model(**over))
     pipeline.IF2dist_new(s, IF)
     s.set_schedule(default_schedule(min_steps), default_fire(), 0.0, 250)
@@ -43,19 +42,71 @@ for cid in cids:
     if embed:
         s.embed(50)
     s.run()
-    ms = s.last_timing()[0]
-    x, e = s.coords(), s.energies()
-    rho = -pipeline.spearman_IF_models(IF, x)
-    order = np.argsort(e[:, 0].astype(np.int64), kind="stable")
-    best = order[0]
-    b = np.linalg.norm(x[best, 1:] - x[best, :-1], axis=1)
-    rg = np.sqrt(((x[best] - x[best].mean(0)) ** 2).sum(1).mean())
-    rr = -pipeline.spearman_IF_pdb(IF, Xr) if Xr is not None and len(Xr) == n else float("nan")
-    rgr = np.sqrt(((Xr - Xr.mean(0)) ** 2).sum(1).mean()) if Xr is not None else float("nan")
-    rows.append((cid, n, s.num_restraints, rho[best], rho.mean(), rho.max(), rr, rho[best] - rr, b.mean(), b.std(), rg, rgr, ms))
+    return s.coords(), s.energies()
+
+
+HEADER = ("| matrix | N | R | rho best | rho rank-matched (rank) | rho mean | rho reference | d best | d matched | ref pct | "
+          "dist-Spearman best / matched / own | dRMSD best / own | bond ours | bond ref | i+2 ours | i+2 ref | Rg ours/ref | ratio | ms |\n"
+          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+
+
+def row(cid, n, R, rep, rank, ms):
+    c, cr = rep["chain"], rep["chain_ref"]
+    return ("| %-12s | %4d | %6d | %.4f | %.4f (%d) | %.4f | %.4f | %+.4f | %+.4f | %.2f | %.3f / %.3f / %.3f | %.2f / %.2f | "
+            "%.2f±%.2f | %.2f±%.2f | %.2f±%.2f | %.2f±%.2f | %.1f / %.1f | %.3f | %.0f |" % (
+                cid, n, R, rep["rho_best"], rep["rho_matched"], rank, rep["rho_mean"], rep["rho_ref"], rep["delta"], rep["delta_matched"],
+                rep["ref_percentile"], rep["sim_best"][0], rep["sim_matched"][0], rep["sim_own"][0], rep["sim_best"][1], rep["sim_own"][1],
+                c[0], c[1], cr[0], cr[1], c[2], c[3], cr[2], cr[3], c[4], cr[4], rep["rg_ratio"], ms))
+
+
+def summary(reps):
+    d = np.array([r["delta"] for r in reps]); dm = np.array([r["delta_matched"] for r in reps])
+    rg = np.array([r["rg_ratio"] for r in reps]); sb = np.array([r["sim_best"][0] for r in reps]); so = np.array([r["sim_own"][0] for r in reps])
+    bsd = np.array([r["chain"][1] - r["chain_ref"][1] for r in reps]); a2 = np.array([r["chain"][2] - r["chain_ref"][2] for r in reps])
+    pct = np.array([r["ref_percentile"] for r in reps])
+    return (f"# {len(d)} matrices: |d best| mean {np.abs(d).mean():.4f} median {np.median(np.abs(d)):.4f} max {np.abs(d).max():.4f}, "
+            f"within 0.01: {(np.abs(d) <= 0.01).sum()}, 0.02: {(np.abs(d) <= 0.02).sum()}, 0.03: {(np.abs(d) <= 0.03).sum()}, bias {d.mean():+.4f}; "
+            f"rank-matched: mean {np.abs(dm).mean():.4f}, within 0.01: {(np.abs(dm) <= 0.01).sum()}, bias {dm.mean():+.4f}; "
+            f"reference inside our replica range (0 < pct < 1): {((pct > 0) & (pct < 1)).sum()}; "
+            f"dist-Spearman ours vs bundled: mean {sb.mean():.4f} min {sb.min():.4f} (ours vs ours: mean {so.mean():.4f} min {so.min():.4f}); "
+            f"Rg ratio mean {rg.mean():.3f} range {rg.min():.3f}-{rg.max():.3f}, within 2%: {(np.abs(rg - 1) <= 0.02).sum()}; "
+            f"bond sd ours-ref mean {bsd.mean():+.3f}; i+2 mean ours-ref {a2.mean():+.3f}")
+
+
+def main():
+    over = json.loads(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].startswith("{") else {}
+    nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    subset = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
+    min_steps = int(over.pop("min_steps", 3000)); quiet = over.pop("quiet", 0); embed = over.pop("embed", 0)
+    seed = int(over.pop("seed", 82364)); dump = over.pop("dump", None)
+    s = Solver(0)
+    reps, t_all, store = [], time.time(), {}
     if not quiet:
-        print("| %-12s | %4d | %6d | %.4f | %.4f | %.4f | %.4f | %+.4f | %.2f±%.2f | %.1f / %.1f | %.0f |" % rows[-1], flush=True)
-d = np.array([r[7] for r in rows if not np.isnan(r[7])])
-print(f"# {len(d)} chromosomes: mean |dSpearman| = {np.abs(d).mean():.4f}, median = {np.median(np.abs(d)):.4f}, "
-      f"within 0.01: {(np.abs(d) <= 0.01).sum()}, within 0.02: {(np.abs(d) <= 0.02).sum()}, within 0.03: {(np.abs(d) <= 0.03).sum()}, "
-      f"max = {np.abs(d).max():.4f}, bias = {d.mean():+.4f}; overrides {over}; total {time.time() - t_all:.1f} s", flush=True)
+        print(HEADER)
+    for cid in all_cids():
+        if subset and not subset.search(cid):
+            continue
+        ref = glob.glob(f"{ALL}/{cid}_rank*_a11.pdb")
+        IF = load(cid)
+        if not ref:
+            continue
+        Xr = load_pdb_xyz(ref[0])
+        if len(Xr) != IF.shape[0]:
+            continue
+        x, e = solve(s, IF, over, nrep, seed, min_steps, embed)
+        ms = s.last_timing()[0]
+        rank = bundled_rank(ref[0])
+        rep = structure_report(IF, x, e[:, 0], Xr, rank)
+        rep["cid"] = cid
+        reps.append(rep)
+        if dump:
+            store[cid] = x; store[cid + "_e"] = e
+        if not quiet:
+            print(row(cid, IF.shape[0], s.num_restraints, rep, rank, ms), flush=True)
+    print(summary(reps) + f"; overrides {over}; seed {seed}; total {time.time() - t_all:.1f} s", flush=True)
+    if dump:
+        np.savez_compressed(dump, **store)
+
+
+if __name__ == "__main__":
+    main()

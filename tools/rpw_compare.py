@@ -1,5 +1,5 @@
 """Debug aid: k_step at every rows-per-wave setting and the cluster kernel (optionally at a forced geometry,
-C3D_CLUSTER_GEOM=CWxRPW) against k_step<rows per wave 2>: all must agree bit for bit."""
+option cluster_geometry in the dict below) against k_step<rows per wave 2>: all must agree bit for bit."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
