@@ -2,8 +2,12 @@
 """Headline benchmark: SA steps/s for 20 replicas of chr1_500kb (N = 455 beads, R = 101426
 restraints) per MI355X — BASELINE.json configs[2], the configuration the metric is quoted on.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--scaling weak|strong] [--dist]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself
+(child processes under torch.distributed.run, before any HIP call) and relays rank 0's line; with WORLD_SIZE set it must
+equal N.  `--dist` initialises the RCCL group even at one rank.  (chromosome3d_amd/launch.py)
 
 A "step" is one SA step (force evaluation + coordinate update) of every replica on the GPU.
 The timed region is exactly K steps of the real annealing schedule, starting W steps in, bracketed
@@ -124,6 +128,63 @@ def hbm_traffic_from_profiles(kernel, n, replicas):
     return best if best else (None, None)
 
 
+def side_figures(device, IF, model, fire, stages, args, B):
+    """Driver-visible second figures (one GPU, rank 0): the precision-matched fp64 leg on the headline workload (the
+    reference's CNS arithmetic is fp64; c3d_f64.hip is the oracle's algorithm in its precision on the GPU) and the
+    step rates of BASELINE configs[1] (chr21_1mb x 20) and configs[4] (synthetic N = 2500 x 8), each from the HIP-event
+    pair around c3d_run_steps on the solver's stream over a whole untimed-by-the-metric anneal."""
+    from chromosome3d_amd import Solver, default_schedule, pipeline
+    from tests.util import load_if, synthetic_if
+    out = {}
+    s = Solver(device)
+    try:
+        # ---- fp64 leg: same workload, same schedule position (W warm-up steps, then K steps), median of 5 regions ----
+        s.set_option("precision", 64)
+        s.set_model(model)
+        pipeline.IF2dist_new(s, IF)
+        s.set_schedule(stages, fire, 0.0, 250)
+        K = min(args.steps, 200)
+        regs = []
+        for rep in range(5):
+            s.init_replicas(REPLICAS, 82364, 0)
+            s.run_steps(max(args.warmup, 1))
+            t0 = time.perf_counter()
+            did = s.run_steps(K)
+            wall = time.perf_counter() - t0
+            regs.append((wall, s.last_timing()[0], did))
+        wall, dev_ms, did = sorted(regs)[len(regs) // 2]
+        v64 = REPLICAS * did / wall
+        out["value_f64"] = round(v64, 1)
+        out["f64"] = {"value": round(v64, 1), "unit": "replica-steps/s", "steps": did, "us_per_step_device": round(1e3 * dev_ms / did, 3),
+                      "frac_f64": round(REPLICAS * B / (1e-3 * dev_ms / did) / 1e9 / HBM_PEAK_GBS, 4), "kernel": s.step_kernel_name,
+                      "note": "option precision=64: k64_force + k64_update per SA step, the oracle's operation order in fp64 (the reference's "
+                              "precision); same B per replica-step, device time from the HIP-event pair on the solver's stream"}
+        out["frac_f64"] = out["f64"]["frac_f64"]
+    finally:
+        s.close()
+    s = Solver(device)
+    try:
+        other = {}
+        for key, name, mat, nrep, nmin in (("config2", "chr21_1mb x 20", load_if("chr21_1mb"), 20, MIN_STEPS),
+                                           ("config5", "synthetic N=2500 x 8 (SURVEY 8d recipe)", synthetic_if(2500)[0], 8, 1000)):
+            n = mat.shape[0]
+            s.set_model(model)
+            pipeline.IF2dist_new(s, mat)
+            s.set_schedule(default_schedule(nmin), fire, 0.0, 250)
+            for _ in range(2):                                         # first pass builds whatever the path needs
+                s.init_replicas(nrep, 82364, 0)
+                s.run_steps(10 ** 7)
+            ms, steps, la = s.last_timing()
+            Bc = 4 * s.num_restraints + 72 * n
+            other[key] = {"workload": name, "n": n, "restraints": s.num_restraints, "replicas": nrep, "sa_steps": steps, "launches": la,
+                          "us_per_step_device": round(1e3 * ms / steps, 3), "replica_steps_per_s": round(nrep * steps / (1e-3 * ms), 1),
+                          "roofline_frac": round(nrep * Bc / (1e-3 * ms / steps) / 1e9 / HBM_PEAK_GBS, 4), "kernel": s.step_kernel_name}
+        out["other_configs"] = other
+    finally:
+        s.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +194,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--dtype", choices=("f32", "f64"), default="f32",
                     help="f64: the fp64 reference step (c3d_f64.hip, written for clarity) instead of the fp32 product kernels")
+    ap.add_argument("--dist", action="store_true", help="initialise the torch.distributed process group even at one rank (RCCL path on a one-GPU box)")
+    ap.add_argument("--no-side-figures", action="store_true", help="skip the f64 leg and the config 2 / config 5 step rates (rank 0, one GPU only)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", type=int, default=REPLICAS, help="weak: per GPU; strong: in all")
@@ -142,26 +205,15 @@ def main():
     args = ap.parse_args()
     reps = args.reps or (50 if args.steps <= 100 else 5)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    torch = None
-    if world > 1:
-        # torch first: its bundled HIP runtime becomes the one libc3d.so binds to
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # C3D_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
-        backend = os.environ.get("C3D_BENCH_BACKEND", "nccl")
-        ndev = torch.cuda.device_count()
-        local_rank = local_rank % max(ndev, 1)
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    on_gpu_group = dist is not None and dist.get_backend() == "nccl"
+    # --gpus N: either the caller started N ranks (WORLD_SIZE == N, checked) or this process starts them as children and
+    # relays their output — before anything here has touched HIP (chromosome3d_amd/launch.py)
+    from chromosome3d_amd import launch
+    rank, local_rank, world = launch.ensure_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__), what="bench.py")
+    # torch (when a group is needed) is imported in there, before libc3d.so: its bundled HIP runtime is the one both bind to.
+    # C3D_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+    dist, coll_dev, local_rank = launch.init_process_group(local_rank, world, force=args.dist)
+    torch = sys.modules.get("torch")
+    on_gpu_group = coll_dev == "cuda"
 
     from chromosome3d_amd import Solver, default_fire, default_model, default_schedule, pipeline, sharding
     from tests.util import load_if
@@ -193,9 +245,11 @@ def main():
 
     def sync_all():
         if dist is not None:
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     # ---- one COMPLETE anneal, untimed by the metric: models for the parity keys, wall-clock per chromosome.  It runs in
     #      calls of K steps like the timed regions, so that every launch of the step kernel in this process covers (about)
@@ -373,7 +427,11 @@ def main():
             "device_ms_full_schedule": round(full_dev_ms, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950
+                         # correction): read from the committed profile named here, NOT collected in this run; scaled from
+                         # that profile's bytes per SA step to this run's SA steps per launch
+                         "traffic": (round(traffic * args.steps / max(launches_per_region, 1e-9)) if traffic is not None else None),
+                         "traffic_unit": "bytes per launch", "traffic_bytes_per_sa_step": traffic, "traffic_source": traffic_src,
                          "kernel": kernel, "avg_launch_us": round(avg_launch_us, 3),
                          "launches_per_region": round(launches_per_region, 2),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch),
@@ -388,6 +446,7 @@ def main():
                      "achieved_tflops": round(M * (30 * R + 40 * n) / (kernel_us_region / args.steps * 1e-6) / 1e12, 2),
                      "peak_tflops": 157.3, "pairs_evaluated_per_replica_step": n * (-(-n // 256) * 256),
                      "note": "every pair is evaluated from both of its rows (16 VALU instructions each); peak = fp32 vector spec"},
+            "collective": {"backend": (dist.get_backend() if dist is not None else None), "device": coll_dev, "world": world},
             "gather_ms": round(gather_ms, 3),
             "models_ranked": len(order),
             "spearman_if_invd_best_ranked": round(-float(allrec[order[0], 2]), 4),
@@ -395,6 +454,8 @@ def main():
             "spearman_reference_model": 0.8722,
             "e_noe_best": round(float(allrec[order[0], 1]), 1),
         }
+        if world == 1 and not args.no_side_figures and args.dtype == "f32":
+            out.update(side_figures(local_rank, IF, model, fire, stages, args, B))
         if not args.no_cpu_baseline and world == 1:          # the CPU leg runs on rank 0 of the one-GPU run only
             v, sample, all_cores = cpu_baseline(IF, d10, model, fire, stages)
             out["cpu_baseline"] = {"value": round(v, 1), "unit": "replica-steps/s", "cores": 1, "kind": "port",

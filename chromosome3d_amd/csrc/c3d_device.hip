@@ -246,7 +246,7 @@ hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuff
 // one workgroup per replica; thread t takes rows t, t+256, ... and the pairs j > i
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_energy(const DevModel m, const float s_noe, const float k_rep,
-                                               const float rep_r2, const float* __restrict__ tgt,
+                                               const double rep_r2, const float* __restrict__ tgt,
                                                const float* __restrict__ xin, double* __restrict__ eout) {
     __shared__ double red[3][256];
     const int rep = blockIdx.x, tid = threadIdx.x;
@@ -290,9 +290,11 @@ __global__ __launch_bounds__(256) void k_energy(const DevModel m, const float s_
     if (tid == 0) { eout[rep * 4 + 0] = red[0][0]; eout[rep * 4 + 1] = red[1][0]; eout[rep * 4 + 2] = red[2][0]; eout[rep * 4 + 3] = 0; }
 }
 
+// rep_r2 = (repel_s r0_rep)^2 formed in double from the float parameters: the reported energies are fp64 quantities, and
+// k (R^2 - r^2)^2 amplifies a float rounding of R^2 (DevStep::rep_r2, which the step kernels use) to 2e-7 relative
 hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe, float k_rep,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(k_energy, dim3(m.nrep), dim3(256), 0, s, m, s_noe, k_rep, p.rep_r2, b.tgt, b.X[parity], b.E);
+                         double rep_r2, hipStream_t s) {
+    hipLaunchKernelGGL(k_energy, dim3(m.nrep), dim3(256), 0, s, m, s_noe, k_rep, rep_r2, b.tgt, b.X[parity], b.E);
     return hipGetLastError();
 }
 

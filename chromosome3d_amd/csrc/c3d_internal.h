@@ -79,7 +79,7 @@ hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, c
 hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float* Fout,
                               bool general_tail, hipStream_t s);
 hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe,
-                         float k_rep, hipStream_t s);
+                         float k_rep, double rep_r2, hipStream_t s);
 hipError_t launch_centre(const DevModel& m, const DevBuffers& b, int parity, hipStream_t s);
 struct StepRun {    // `count` consecutive steps with the same parameters
     DevStep p;

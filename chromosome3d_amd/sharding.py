@@ -50,8 +50,9 @@ def gather_records(rec, device=None):
         return rec[np.argsort(rec[:, 0], kind="stable")]
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rec[np.argsort(rec[:, 0], kind="stable")]
+    # an initialised group of ONE rank still goes through the collectives (bench.py --dist: the RCCL path on a one-GPU box)
     world = dist.get_world_size()
     dev = device if device is not None else "cpu"
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]

@@ -364,6 +364,25 @@ void c3o_init_coords(const c3o_model* m, uint64_t seed, uint32_t replica, double
     cx /= n; cy /= n; cz /= n;
     for (int i = 0; i < n; ++i) { x[3 * i] -= cx; x[3 * i + 1] -= cy; x[3 * i + 2] -= cz; }
 }
+/* A5, the reference's start structure restated for beads: extn.inp lays the chain out along x (`ident (x) (all)`,
+ * `do (x=x/5.)`, chromosome3D.pl:2413-2414), gives every atom a random y and z in [0, 0.5) (`do (y=random(0.5))`,
+ * `do (z=random(0.5))`, :2415-2416) and regularises the result to covalent geometry (:2424-2517).  Bead i sits b0 * i along x
+ * (the regularised Calpha spacing), y and z uniform in [0, 0.5) from Philox words 0 and 1 of counter (i, purpose 2) under the
+ * replica's key; centred like the coil start. */
+void c3o_init_coords_extended(const c3o_model* m, uint64_t seed, uint32_t replica, double* x) {
+    const int n = m->n;
+    const uint32_t key[2] = {(uint32_t)(seed & 0xFFFFFFFFu) ^ (replica * 0x9E3779B9u), (uint32_t)(seed >> 32) + replica};
+    for (int i = 0; i < n; ++i) {
+        const uint32_t ctr[4] = {(uint32_t)i, 2u, 0u, 0u};
+        uint32_t u[4];
+        c3o_philox4x32(ctr, key, u);
+        x[3 * i] = m->b0 * i; x[3 * i + 1] = 0.5 * u01(u[0]); x[3 * i + 2] = 0.5 * u01(u[1]);
+    }
+    double cx = 0, cy = 0, cz = 0;
+    for (int i = 0; i < n; ++i) { cx += x[3 * i]; cy += x[3 * i + 1]; cz += x[3 * i + 2]; }
+    cx /= n; cy /= n; cz /= n;
+    for (int i = 0; i < n; ++i) { x[3 * i] -= cx; x[3 * i + 1] -= cy; x[3 * i + 2] -= cz; }
+}
 /* v ~ Maxwell(T): sigma = sqrt(kB T * ACCEL / m)  [A/ps]   (deck :1646-1648, T = 0.5 K) */
 void c3o_init_velocities(const c3o_model* m, uint64_t seed, uint32_t replica, double temp, double* v) {
     const double sigma = sqrt(KBOLTZ * temp * ACCEL / m->mass);

@@ -70,6 +70,7 @@ def lib():
         L.c3o_energy_force.argtypes = [C.POINTER(Model), i32p, dp, C.c_double, C.c_double, C.c_double, dp, C.POINTER(Energy)]
         L.c3o_energy_force.restype = None
         L.c3o_init_coords.argtypes = [C.POINTER(Model), C.c_uint64, C.c_uint32, dp]
+        L.c3o_init_coords_extended.argtypes = [C.POINTER(Model), C.c_uint64, C.c_uint32, dp]
         L.c3o_init_velocities.argtypes = [C.POINTER(Model), C.c_uint64, C.c_uint32, C.c_double, dp]
         L.c3o_md_step.argtypes = [C.POINTER(Model), i32p, C.POINTER(Stage), dp, dp, dp]
         L.c3o_fire_step.argtypes = [C.POINTER(Model), i32p, C.POINTER(Stage), C.POINTER(FireParams), C.POINTER(FireState), dp, dp, dp, dp]
@@ -167,9 +168,10 @@ def energy_force(model, tgt10, x, w_all=1.0, w_vdw=1.0, repel_s=1.0):
     return F, (e.e_noe, e.e_bond, e.e_rep)
 
 
-def init_coords(model, seed, replica):
+def init_coords(model, seed, replica, start=0):
+    """start 0: random coil; 1: the extended strand of extn.inp (chromosome3D.pl:2413-2416) at bead level"""
     x = np.zeros((model.n, 3))
-    lib().c3o_init_coords(C.byref(model), seed, replica, _dp(x))
+    (lib().c3o_init_coords_extended if start == 1 else lib().c3o_init_coords)(C.byref(model), seed, replica, _dp(x))
     return x
 
 

@@ -65,3 +65,76 @@ def test_two_ranks_rehearsal(mode, counts):
     assert d["models_ranked"] == sum(counts)
     assert ("weak_scaling_value" in d) == (mode == "strong")
     assert abs(d["spearman_if_invd_best_ranked"] - d["spearman_reference_model"]) <= 0.01
+
+
+# ---- how bench.py / the batch driver get their ranks (chromosome3d_amd/launch.py) --------------------------------------
+def test_gpus_flag_fails_loudly_without_that_many_gpus():
+    """`python bench.py --gpus 2` on a machine with fewer than 2 GPUs (this container: none; the one-GPU box: one) stops with a
+    message naming the shortfall instead of running one rank and calling it two.  Runs before anything touches HIP."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "C3D_BENCH_BACKEND")}
+    for cmd in ([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"], ["-m", "chromosome3d_amd.batch", "--gpus", "2"]):
+        p = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+        import torch
+        if torch.cuda.device_count() >= 2:
+            pytest.skip("this machine has two GPUs")
+        assert p.returncode != 0 and "--gpus 2" in p.stderr and "GPU(s)" in p.stderr, (p.returncode, p.stderr[-500:])
+        assert '"metric"' not in p.stdout
+
+
+def test_world_size_must_match_the_gpus_flag():
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK")}, WORLD_SIZE="4", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
+
+
+def test_launcher_rank_bookkeeping(monkeypatch):
+    from chromosome3d_amd import launch
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert launch.ensure_ranks(1, []) == (0, 0, 1)
+    monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "5"); monkeypatch.setenv("LOCAL_RANK", "5")
+    assert launch.ensure_ranks(8, []) == (5, 5, 8)
+    with pytest.raises(SystemExit):
+        launch.ensure_ranks(4, [])
+
+
+@pytest.mark.gpu
+def test_bench_through_rccl_at_one_rank():
+    """`--dist`: init_process_group("nccl"), the all_reduce(MAX) of the region times on the device and the device-side
+    all_gather of the model records all execute on this box's one MI355X (the N > 1 case is the same code over more ranks)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "C3D_BENCH_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist", "--steps", "20", "--warmup", "5", "--reps", "5",
+                        "--no-cpu-baseline", "--no-side-figures"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["replicas_per_gpu"] == [20] and d["models_ranked"] == 20
+    assert d["collective"] == {"backend": "nccl", "device": "cuda", "world": 1}
+    assert 2.0e6 < d["value"] < 1.0e7
+
+
+@pytest.mark.gpu
+def test_two_ranks_started_by_bench_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts both ranks (children under torch.distributed.run) and
+    relays rank 0's line.  gloo rehearsal: this box has one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["C3D_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--reps", "5",
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["replicas_per_gpu"] == [20, 20] and d["collective"]["backend"] == "gloo"
+
+
+@pytest.mark.gpu
+def test_side_figures_ride_in_the_one_gpu_line():
+    """The driver's line (one GPU) also carries the precision-matched fp64 leg and the step rates of configs 2 and 5."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--reps", "5", "--no-cpu-baseline"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    assert 3e5 < d["value_f64"] < d["value"] and 0.01 < d["frac_f64"] < 0.2 and "k64" in d["f64"]["kernel"]
+    c2, c5 = d["other_configs"]["config2"], d["other_configs"]["config5"]
+    assert c2["n"] == 37 and c2["replicas"] == 20 and 0.5 < c2["us_per_step_device"] < 5.0
+    assert c5["n"] == 2500 and c5["replicas"] == 8 and c5["restraints"] == 3113760 and 10.0 < c5["us_per_step_device"] < 60.0
+    r = d["roofline"]
+    assert r["traffic_unit"] == "bytes per launch" and r["traffic"] == round(r["traffic_bytes_per_sa_step"] * 20)

@@ -122,5 +122,10 @@ def test_chromosome_sharded_batch_world2():
         expect.append(sorted(range(6), key=lambda r: (int(e[r]), r)))  # ascending int(E_noe), ties by replica id
     assert res[0][2] == expect
     # the restraint-count cost of the bundled 500 kb matrices is what BASELINE.md lists
-    m = batch.load_matrices(os.path.join(ROOT, "tests", "golden", "all45"), "_500kb")
-    assert len(m) == 22 and list(m)[0] == "chr1_500kb" and batch.job_costs(m)[0] == 450 * 451 // 2
+    st = set()
+    m = batch.load_matrices(os.path.join(ROOT, "tests", "golden", "all45"), "_500kb", st)
+    # 22 shipped + the chr2_500kb stand-in (N = 479, the largest job): the 23 chromosomes of test.sh:9-12
+    assert len(m) == 23 and list(m)[:2] == ["chr1_500kb", "chr2_500kb"] and st == {"chr2_500kb"}
+    assert batch.job_costs(m)[0] == 450 * 451 // 2 and batch.job_costs(m)[1] == 474 * 475 // 2
+    from chromosome3d_amd import sharding
+    assert sharding.lpt_assign(batch.job_costs(m), 8)[0][0] == 1          # the biggest job opens rank 0's list

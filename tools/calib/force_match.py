@@ -57,7 +57,7 @@ def prepare(sel=None, free=(1, 2)):
         if sel and not re.search(sel, cid):
             continue
         ref = glob.glob(f"{ALL}/{cid}_rank*_a11.pdb")
-        if not ref:
+        if not ref or "standin" in np.load(f"{ALL}/{cid}_upper.npz").files:      # chr2_500kb: the matrix is a stand-in built FROM the model
             continue
         IF = load(cid); n = len(IF); X = load_pdb_xyz(ref[0])
         if len(X) != n:
