@@ -101,6 +101,7 @@ struct c3d_ctx {
     c3d_fire_params fire;
     float gtol = 0.0f;
     int check_every = 250;
+    bool zero_weight = false;              // some stage has w_all = 0: its steps take the general kernels, no cluster launches
     bool use_graph = true;
     int rpw = 2;
     int stage_dma = 1;
@@ -207,6 +208,7 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
     m.tail_c = h.asym * h.rswitch;
     m.tail_b = (m.tail_c - 2.0f * h.rswitch) * h.rswitch * h.rswitch;
     m.mrs = h.mrswitch; m.nmrs = -h.mrswitch;
+    m.inv_rs = 1.0f / h.rswitch; m.nm_rs = -h.mrswitch / h.rswitch;
     m.mtail_c = h.masym;
     m.mtail_b = (m.mtail_c - 2.0f * h.mrswitch) * h.mrswitch * h.mrswitch;
     m.k_bond2 = 2.0f * h.k_bond; m.b0 = h.b0;
@@ -223,6 +225,8 @@ bool general_tail(const c3d::DevModel& m) {
     if (!(m.tail_b == 0.0f && m.tail_c == 2.0f * m.rs)) return true;
     return m.noe_pot == 3 && !(m.mtail_b == 0.0f && m.mtail_c == 2.0f * m.mrs);
 }
+// the kernels of the general form also serve a step whose restraint weight is zero (the clamp form divides by it)
+bool general_step(const c3d::DevModel& m, const c3d::DevStep& p) { return general_tail(m) || p.w_rs == 0.0f; }
 c3d::DevFire dev_fire(const c3d_ctx* c) {
     c3d::DevFire f;
     f.dt_start = c->fire.dt_start; f.dt_max = c->fire.dt_max; f.f_inc = c->fire.f_inc; f.f_dec = c->fire.f_dec;
@@ -239,6 +243,10 @@ c3d::DevStep dev_step(const c3d_ctx* c, int kind, float dt, float w_all, float w
     p.rep_r2 = rr * rr;
     p.inv_rep_r2 = rr > 0.0f ? 1.0f / p.rep_r2 : 0.0f;
     p.w_rep4r2 = p.w_rep4 * p.rep_r2;
+    // clamp form (c3d_step_core.h pair_term): the NOE weight times rswitch is applied once per row, the repel weight rides
+    // relative to it.  A stage without restraint weight (w_all = 0) cannot be written that way: general kernels (zero_weight).
+    p.w_rs = p.w_noe2n * c->model.rswitch;
+    p.kq = p.w_rs != 0.0f ? p.w_rep4r2 / p.w_rs : 0.0f;
     p.t_bath = t_bath;
     return p;
 }
@@ -260,6 +268,8 @@ void build_program(c3d_ctx* c) {
         prev_kind = st.kind;
     }
     c->pc = 0;
+    c->zero_weight = false;
+    for (const Op& op : c->program) c->zero_weight = c->zero_weight || op.p.w_rs == 0.0f;
     drop_graphs(c);
     // run-length code of the whole program (a FIRE stage is 2 runs, the cool ramp 81) for the cluster kernel
     c->prog_runs.clear();
@@ -328,14 +338,14 @@ int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
     c3d::DevModel m = dev_model(c);
     group_range(c, g, m.rep_base, m.nrep_g);
     hipError_t e = use_sym(c) ? c3d::launch_step_sym(m, op.p, dev_fire(c), c->buf, par, c->d_sym_tiles, c->d_sym_scratch, c->gstream[g])
-                              : c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, general_tail(m), c->gstream[g]);
+                              : c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, general_step(m, op.p), c->gstream[g]);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
     return C3D_OK;
 }
 
 // Can the ops run as one k_cluster launch (a replica on a few 1024-thread workgroups of one XCD)?
 bool cluster_ok(c3d_ctx* c) {
-    if (!c->resident || !c->cluster || !c->cl_ok || !c->d_crec) return false;
+    if (!c->resident || !c->cluster || !c->cl_ok || !c->d_crec || c->zero_weight) return false;
     return !general_tail(dev_model(c));
 }
 
@@ -1199,12 +1209,12 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     static thread_local char buf[96];
     if (!c) return "";
     const c3d::DevModel m = dev_model(c);
-    const char* gen = general_tail(m) ? "true" : "false";
+    const char* gen = (general_tail(m) || c->zero_weight) ? "true" : "false";
     const char* rs1 = (!general_tail(m) && m.rs == 1.0f) ? "true" : "false";
-    if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %s>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, rs1);
+    if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d>", m.noe_pot, c->cl_plan.rpw, m.npad / 256);
     else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);
     else if (c->precision == 64) snprintf(buf, sizeof(buf), "c3d::k64_force");
-    else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d, %s>", m.noe_pot, gen, m.rpw, rs1);
+    else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d>", m.noe_pot, gen, m.rpw);
     return buf;
 }
 
@@ -1214,7 +1224,7 @@ extern "C" int c3d_eval(c3d_ctx* c, float w_all, float w_vdw, float repel_s, flo
     const c3d::DevModel m = dev_model(c);
     const c3d::DevStep p = dev_step(c, 3, 0.0f, w_all, w_vdw, repel_s, 0.0f);
     if (F) {
-        hipError_t err = c3d::launch_eval_forces(m, p, c->buf, c->parity, c->d_feval, general_tail(m), c->stream);
+        hipError_t err = c3d::launch_eval_forces(m, p, c->buf, c->parity, c->d_feval, general_step(m, p), c->stream);
         if (err != hipSuccess) return fail(C3D_ERR_HIP, std::string("eval launch: ") + hipGetErrorString(err));
         int rc = get_soa(c, c->d_feval, F);
         if (rc) return rc;

@@ -52,7 +52,7 @@ __device__ unsigned long long g_cstamps[64][8];
 #define CSTAMP_C(k) do { } while (0)
 #endif
 
-template <int POT, int RPW, int NB, bool RS1>
+template <int POT, int RPW, int NB>
 __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const AnnealIO* __restrict__ io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
     const StepRun* __restrict__ runs, const int run0, const int skip0, const int nsteps, const unsigned tag_base,
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     float* cbuf = fbuf + 3 * 64;                  // [3][64] chain sums of this workgroup's rows (H1..H3 -> H0)
     float* dump = cbuf + 3 * 64;                  // [4] nobody reads
     int* s_slot = reinterpret_cast<int*>(dump + 4);
-    float4* mwbuf = reinterpret_cast<float4*>(dump + 8);   // [CW][RPW * NB][64] NOE weights of the current run
+    // dump + 8 ..: [CW][RPW * NB][64] float4, the compute waves' pair_a constants
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = (CW + NH) * 64;           // NH helper waves: H0 + (NH - 1) chain helpers
     const int RW = CW * RPW;                      // rows of one workgroup: a multiple of 8 (whole tiles), <= 64
@@ -101,13 +101,22 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, (int)(sizeof(u32x4) * 2 * m.nrep_g * units), 0x00020000);
 
     // ---- prologue: everything that stays for the whole launch --------------------------------------
+    // per-pair constants of the clamp form (c3d_step_core.h: pair_b = target / rswitch in registers, pair_a = 1 / rswitch where
+    // a restraint exists in wave-private LDS), the same for every step of the launch
     float4 tv[RPW][NB];
+    float4* const mw = reinterpret_cast<float4*>(dump + 8) + (size_t)(is_compute ? cwave : 0) * (RPW * NB * 64);
+    {
+        DevStep p0{};
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
+        for (int r = 0; r < RPW; ++r)
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
-            tv[r][jb] = is_compute ? *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * NPAD + 256 * jb + 4 * lane)
-                                   : make_float4(0, 0, 0, 0);
+            for (int jb = 0; jb < NB; ++jb) {
+                const float4 t = is_compute ? *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * NPAD + 256 * jb + 4 * lane)
+                                            : make_float4(0, 0, 0, 0);
+                tv[r][jb] = pair_b<false>(m, t);
+                if (is_compute) mw[(r * NB + jb) * 64 + lane] = pair_a<false>(m, p0, t);
+            }
+    }
     float vcx = 0.0f, vcy = 0.0f, vcz = 0.0f;     // H0: velocity of this lane's row, carried from step to step
     FireState st;
     {
@@ -151,14 +160,6 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
       const DevStep p = runs[run].p;
       const int count = runs[run].count;
       const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
-      // NOE weight of every pair of this wave for this run (-2 w S or 0): wave-private LDS, no barrier needed
-      float4* const mw = mwbuf + (size_t)(is_compute ? cwave : 0) * (RPW * NB * 64);
-      if (is_compute) {
-#pragma unroll
-          for (int r = 0; r < RPW; ++r)
-#pragma unroll
-              for (int jb = 0; jb < NB; ++jb) mw[(r * NB + jb) * 64 + lane] = noe_weights(p, tv[r][jb]);
-      }
       for (int it = run == run0 ? skip0 : 0; it < count; ++it, ++s) {
         __syncthreads();                            // B1: xs/ys/zs/ps of this step are in LDS
         CSTAMP(0);                                  // step start (H0 past B1)
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             // ---- K2: pair terms of RPW rows, butterfly sums, three words per row for H0 ------------------
             if (p.kind != 4) {
                 float Fx, Fy, Fz;
-                tile_pair_sums_reg<POT, RPW, NB, true, RS1>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
+                tile_pair_sums_reg<POT, RPW, NB, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
                 if (lane < RPW) {
                     const int k = cwave * RPW + lane;
                     fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz;
@@ -221,7 +222,11 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             float xn = 0.0f, yn = 0.0f, zn = 0.0f;
             if (hfin) {
                 float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
-                if (p.kind != 4) { Fx = fbuf[lane] + cbuf[lane]; Fy = fbuf[64 + lane] + cbuf[64 + lane]; Fz = fbuf[128 + lane] + cbuf[128 + lane]; }
+                if (p.kind != 4) {
+                    Fx = pair_sum_scaled<false>(p, fbuf[lane]) + cbuf[lane];
+                    Fy = pair_sum_scaled<false>(p, fbuf[64 + lane]) + cbuf[64 + lane];
+                    Fz = pair_sum_scaled<false>(p, fbuf[128 + lane]) + cbuf[128 + lane];
+                }
                 float vx0 = vcx, vy0 = vcy, vz0 = vcz;
                 if (p.kind == 3) { vx0 = vy0 = vz0 = 0.0f; }
                 else if (p.kind == 4) { C3D_HROW_INDEX; const float* vinit = io->vinit; vx0 = vinit[ix]; vy0 = vinit[iy]; vz0 = vinit[iz]; }
@@ -366,7 +371,7 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
 
 size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl) { return (size_t)2 * m.nrep_g * pl.parts * pl.units * 16; }
 
-template <int POT, int RPW, int NB, bool RS1>
+template <int POT, int RPW, int NB>
 static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
                              const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                              hipStream_t s) {
@@ -375,15 +380,15 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
     static std::atomic<bool> attr_set[64];
     const int dev = pl.device & 63;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, RS1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev].store(true, std::memory_order_release);
     }
     if (pl.t0 && pl.t1)
-        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, RS1>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
+        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
                               reinterpret_cast<u32x4*>(rec), runs, run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, m, fp);
     else
-        hipLaunchKernelGGL((k_cluster<POT, RPW, NB, RS1>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
+        hipLaunchKernelGGL((k_cluster<POT, RPW, NB>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
                            run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, m, fp);
     return hipGetLastError();
 }
@@ -392,9 +397,7 @@ static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const Clust
                                const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                                hipStream_t s) {
 #define C3D_CL(R, B)                                                                                                    \
-    if (pl.rpw == R && m.npad == 256 * B)                                                                               \
-        return m.rs == 1.0f ? cluster_go<POT, R, B, true>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s) \
-                            : cluster_go<POT, R, B, false>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s)
+    if (pl.rpw == R && m.npad == 256 * B) return cluster_go<POT, R, B>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s)
     C3D_CL(1, 1); C3D_CL(1, 2); C3D_CL(1, 3); C3D_CL(1, 4);
     C3D_CL(2, 1); C3D_CL(2, 2); C3D_CL(2, 3); C3D_CL(2, 4);
     C3D_CL(3, 1); C3D_CL(3, 2);

@@ -59,7 +59,7 @@ inline dim3 grid_blocks(const DevModel& m) { return dim3(8, m.nrep_g, (m.ntiles 
 //   4. lanes 0..RPW-1 finish one row each; tile partial sums through LDS
 // ---------------------------------------------------------------------------------------------
 
-template <int POT, bool GEN, int RPW, bool RS1>
+template <int POT, bool GEN, int RPW>
 __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     const float* __restrict__ pin, const float* __restrict__ xin, const float* __restrict__ tgt,
     const float* __restrict__ vin, const float* __restrict__ vinit, const FireState* __restrict__ sin,
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
 
     // ---- 3. K2: pair forces for this wave's rows ---------------------------------------------
     float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
-    if (p.kind != 4) tile_forces<POT, GEN, RPW, RS1>(m, p, tgt, xs, ys, zs, row0, lane, tv, Fx, Fy, Fz);
+    if (p.kind != 4) tile_forces<POT, GEN, RPW>(m, p, tgt, xs, ys, zs, row0, lane, tv, Fx, Fy, Fz);
 
     C3D_STAMP(4);
     // ---- 4. epilogue: lanes 0..RPW-1 finish one row each --------------------------------------
@@ -162,13 +162,8 @@ template <int POT, bool GEN, int RPW>
 static hipError_t launch_step_r(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
                                 hipStream_t s) {
     const int q = par ^ 1;
-    // RS1: the CNS-default switch distance of 1 A (rs / d is the reciprocal distance itself); only the default tail has it
-    if (!GEN && m.rs == 1.0f)
-        hipLaunchKernelGGL((k_step<POT, GEN, RPW, !GEN>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
-                           b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
-    else
-        hipLaunchKernelGGL((k_step<POT, GEN, RPW, false>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
-                           b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
+    hipLaunchKernelGGL((k_step<POT, GEN, RPW>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
+                       b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
     return hipGetLastError();
 }
 template <int POT, bool GEN>

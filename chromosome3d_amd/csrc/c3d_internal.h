@@ -27,6 +27,7 @@ struct DevModel {
     float rs, tail_c, tail_b;      // soft tail: dE/dD = tail_c - tail_b / D^2  (D > rs)
     float mrs, mtail_c, mtail_b;   // noe_pot 3, lower side: dE/dD = mtail_c - mtail_b / D^2  (D = t - d > mrs)
     float nmrs;                    // -mrs
+    float inv_rs, nm_rs;           // 1 / rs, -mrs / rs: the clamp form works on (d - t) / (rs d), see pair_term
     float k_bond2, b0;             // 2*k_bond
     float k_ang2, a0;              // 2*k_ang
     float acc;                     // kAccel / mass
@@ -44,6 +45,8 @@ struct DevStep {
     float rep_r2;    // (repel_s * r0_rep)^2
     float inv_rep_r2;// 1 / rep_r2
     float w_rep4r2;  // w_rep4 * rep_r2
+    float w_rs;      // w_noe2n * rs: the factor the clamp form leaves out of every pair term and applies once per row
+    float kq;        // w_rep4r2 / w_rs: the repel weight relative to it (w_noe2n != 0; else the general kernels run)
     float t_bath;
 };
 

@@ -113,57 +113,86 @@ __device__ __forceinline__ void tile_prefetch(const DevModel& m, const float* __
         tv[r] = *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 256 * jb + 4 * lane);
 }
 
-// One pair term.  F_i += c * (x_i - x_j) with c = -(dE/dd)/d.  Written to minimise VALU issue slots: the solver is
-// bound by the vector ALU (a wave issues one VALU instruction per ~5 ns, the pipe takes 1.2-3.5 ns per instruction by its form; tools/microbench/valu_forms), so every
-// instruction of this function costs ~1.4 ns x pairs / lanes on the whole chip:
+// One pair term.  F_i += c * (x_i - x_j) with c = -(dE/dd)/d.  Written to minimise VALU issue slots: the solver is bound by
+// the vector ALU (a wave issues one VALU instruction per ~5 ns, the pipe takes 1.2-3.5 ns per instruction by its form;
+// tools/microbench/valu_forms, pair_loop_v2), so every instruction of this function costs ~1.5 ns x pairs / lanes on the chip.
 //   r2 carries a +1e-12 guard inside the fma chain (no separate max);
-//   NOE, CNS-default tail (slope 2 rs): with u = (d - t)/d = 1 - t/d the clamp of the soft-square acts on
-//   u directly: -(dE/dd)/d = -2 w S min(u, rs/d)  (d itself is never formed); RS1: rs == 1, rs/d is rinv itself;
-//   mw = -2 w S where the pair is restrained, 0 where it is not: mask and weight are ONE multiply (the resident
-//   kernels keep mw in registers per run of equal steps, the per-step kernel forms it from the target);
 //   repel: max(0, R2 - r2) = R2 * clamp01(1 - r2/R2) is ONE v_fma_f32 with the clamp output modifier.
-template <int POT, bool GEN, bool RS1>
-__device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, float v, float mw, float dx, float dy, float dz,
-                                          float& fx, float& fy, float& fz) {
+// Clamp form (!GEN: tail slope 2 rs above, 2 mrs below for POT 3), 15 instructions:
+//   with u = (d - t)/d = 1 - t/d the soft-square's clamp acts on u directly, -(dE/dd)/d = W clamp(u, -mrs/d, rs/d), W = -2 w S
+//   (d itself is never formed).  Divided through by rs:  u/rs = a - b/d  with b = t/rs and a = 1/rs per pair (b = a = 0 where
+//   no restraint exists: the term vanishes by itself, no mask multiply), bounds (-mrs/rs)/d and 1/d = rinv itself; and the
+//   weight W rs is left out of the pair term altogether: c' = clamp(...) + kq * q01 with kq = (repel weight)/(W rs), the
+//   row's sum of c' * (x_i - x_j) is multiplied by W rs ONCE after the reduction (row_total).  b and a are per-pair
+//   constants of a whole launch (cluster kernel: registers / LDS) or two instructions from the streamed target (k_step).
+// General tails (GEN): v = target in Angstrom, mw = W where restrained else 0, dE/dd from noe_grad; nothing is left out.
+// the three run constants of the clamp form, held in VGPRs by the tile functions (an SGPR source costs the instruction a
+// second issue cycle on gfx950: 2.25 against 1.17 ns, tools/microbench/valu_forms)
+struct PairK {
+    float inv_rep_r2, kq, nm_rs;
+};
+__device__ __forceinline__ PairK pair_k(const DevModel& m, const DevStep& p) {
+    PairK k{p.inv_rep_r2, p.kq, m.nm_rs};
+    asm volatile("" : "+v"(k.inv_rep_r2), "+v"(k.kq), "+v"(k.nm_rs));
+    return k;
+}
+template <int POT, bool GEN>
+__device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, const PairK& k, float v, float mw, float dx, float dy,
+                                          float dz, float& fx, float& fy, float& fz) {
     const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, 1e-12f)));
     const float rinv = __builtin_amdgcn_rsqf(r2);
-    float s;   // (dE/dd) / (2 d) without the weights
-    if constexpr (!GEN) {
-        const float u = fmaf(-v, rinv, 1.0f);          // (d - t) / d
-        float lim;                                     // rs / d
-        if constexpr (RS1) lim = rinv; else lim = m.rs * rinv;
-        if constexpr (POT == 1) s = fminf(u, lim);
-        else if constexpr (POT == 0) s = fminf(fmaxf(u, -lim), lim);
-        else if constexpr (POT == 3) s = __builtin_amdgcn_fmed3f(u, m.nmrs * rinv, lim);   // clamp(u, -mrs/d, rs/d): one v_med3_f32
-        else s = u;
-    } else {
-        s = 0.5f * noe_grad<POT, GEN>(r2 * rinv - v, m) * rinv;
-    }
-    float c = mw * s;
+    float q01;   // clamp01(1 - r2/R2): the clamp is an output modifier of the fma (hipcc has no builtin for it)
+    asm("v_fma_f32 %0, -%1, %2, 1.0 clamp" : "=v"(q01) : "v"(r2), "v"(k.inv_rep_r2));
     // repel on EVERY column: padding beads are 1e4 A away (q = 0), the self term has dx = 0, and the
     // |i-j| < rep_sep neighbours are taken back out in the chain-term pass below
-    float q01;   // clamp01(1 - r2/R2): the clamp is an output modifier of the fma (hipcc has no builtin for it)
-    asm("v_fma_f32 %0, -%1, %2, 1.0 clamp" : "=v"(q01) : "v"(r2), "v"(p.inv_rep_r2));
-    c = fmaf(p.w_rep4r2, q01, c);                      // 4 w_vdw k_rep R2 * clamp01(1 - r2/R2)
+    float c;
+    if constexpr (!GEN) {
+        const float u = fmaf(-v, rinv, mw);            // (d - t) / (rs d); v = t / rs, mw = 1 / rs (both 0: no restraint)
+        float s;
+        if constexpr (POT == 1) s = fminf(u, rinv);
+        else if constexpr (POT == 0) s = __builtin_amdgcn_fmed3f(u, -rinv, rinv);
+        else if constexpr (POT == 3) s = __builtin_amdgcn_fmed3f(u, k.nm_rs * rinv, rinv);   // clamp(u, -mrs/(rs d), 1/d): one v_med3_f32
+        else s = u;
+        c = fmaf(k.kq, q01, s);
+    } else {
+        const float s = 0.5f * noe_grad<POT, GEN>(r2 * rinv - v, m) * rinv;   // (dE/dd) / (2 d) without the weights
+        c = fmaf(p.w_rep4r2, q01, mw * s);             // 4 w_vdw k_rep R2 * clamp01(1 - r2/R2)
+    }
     fx = fmaf(c, dx, fx);
     fy = fmaf(c, dy, fy);
     fz = fmaf(c, dz, fz);
 }
+// a row's pair force from the reduced sum of its pair terms: the clamp form's common factor comes back here
+template <bool GEN>
+__device__ __forceinline__ float pair_sum_scaled(const DevStep& p, float fsum) {
+    if constexpr (GEN) return fsum; else return p.w_rs * fsum;
+}
 
-// per-pair NOE weights of four targets: -2 w S where a restraint exists (target > 0), else 0
+// per-pair constants of four targets (Angstrom, 0 = none).  Clamp form: (t / rs, 1 / rs or 0); general tails: (t, W or 0)
+template <bool GEN>
+__device__ __forceinline__ float4 pair_b(const DevModel& m, const float4 tv) {
+    if constexpr (GEN) return tv; else return make_float4(tv.x * m.inv_rs, tv.y * m.inv_rs, tv.z * m.inv_rs, tv.w * m.inv_rs);
+}
+template <bool GEN>
+__device__ __forceinline__ float4 pair_a(const DevModel& m, const DevStep& p, const float4 tv) {
+    const float on = GEN ? p.w_noe2n : m.inv_rs;
+    return make_float4(tv.x > 0.0f ? on : 0.0f, tv.y > 0.0f ? on : 0.0f, tv.z > 0.0f ? on : 0.0f, tv.w > 0.0f ? on : 0.0f);
+}
+// (kept for the symmetric-tile kernels, which evaluate the round-2 form) -2 w S where a restraint exists (target > 0), else 0
 __device__ __forceinline__ float4 noe_weights(const DevStep& p, const float4 tv) {
     return make_float4(tv.x > 0.0f ? p.w_noe2n : 0.0f, tv.y > 0.0f ? p.w_noe2n : 0.0f, tv.z > 0.0f ? p.w_noe2n : 0.0f,
                        tv.w > 0.0f ? p.w_noe2n : 0.0f);
 }
 
-// the four pair terms of one lane and one row against columns j .. j+3 (targets tv, weights mw)
-template <int POT, bool GEN, bool RS1>
-__device__ __forceinline__ void pair_quad(const DevModel& m, const DevStep& p, const float4 tv, const float4 mw, float xi, float yi,
-                                          float zi, const float4 xj, const float4 yj, const float4 zj, float& fx, float& fy, float& fz) {
-    pair_term<POT, GEN, RS1>(m, p, tv.x, mw.x, xi - xj.x, yi - yj.x, zi - zj.x, fx, fy, fz);
-    pair_term<POT, GEN, RS1>(m, p, tv.y, mw.y, xi - xj.y, yi - yj.y, zi - zj.y, fx, fy, fz);
-    pair_term<POT, GEN, RS1>(m, p, tv.z, mw.z, xi - xj.z, yi - yj.z, zi - zj.z, fx, fy, fz);
-    pair_term<POT, GEN, RS1>(m, p, tv.w, mw.w, xi - xj.w, yi - yj.w, zi - zj.w, fx, fy, fz);
+// the four pair terms of one lane and one row against columns j .. j+3 (per-pair constants tb, ta: pair_b / pair_a)
+template <int POT, bool GEN>
+__device__ __forceinline__ void pair_quad(const DevModel& m, const DevStep& p, const PairK& k, const float4 tb, const float4 ta, float xi,
+                                          float yi, float zi, const float4 xj, const float4 yj, const float4 zj, float& fx, float& fy,
+                                          float& fz) {
+    pair_term<POT, GEN>(m, p, k, tb.x, ta.x, xi - xj.x, yi - yj.x, zi - zj.x, fx, fy, fz);
+    pair_term<POT, GEN>(m, p, k, tb.y, ta.y, xi - xj.y, yi - yj.y, zi - zj.y, fx, fy, fz);
+    pair_term<POT, GEN>(m, p, k, tb.z, ta.z, xi - xj.z, yi - yj.z, zi - zj.z, fx, fy, fz);
+    pair_term<POT, GEN>(m, p, k, tb.w, ta.w, xi - xj.w, yi - yj.w, zi - zj.w, fx, fy, fz);
 }
 
 // One chain term: neighbour nb (0..3 = offsets -2,-1,+1,+2) of `row`: pseudo-bond (i,i+-1), pseudo-angle (i,i+-2) and the
@@ -201,13 +230,13 @@ __device__ __forceinline__ float quad_chain_sum(float c) {
 // Here (per-step kernel, forces hook): rows row0 .. row0+RPW-1 of one wave.  Chain terms: neighbour nb of row i is
 // evaluated by lane 4 (i & 1) + nb, two rows per pass; the quad sums are then brought to lane r = i - row0, the row's
 // finisher (lanes 0 .. RPW-1).
-template <int RPW>
+template <int RPW, bool GEN>
 __device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevStep& p, const float* xs, const float* ys,
                                                  const float* zs, int row0, int lane, float (&fx)[RPW], float (&fy)[RPW],
                                                  float (&fz)[RPW], float& Fx, float& Fy, float& Fz) {
-    Fx = reduce_rows<RPW>(fx, lane);
-    Fy = reduce_rows<RPW>(fy, lane);
-    Fz = reduce_rows<RPW>(fz, lane);
+    Fx = pair_sum_scaled<GEN>(p, reduce_rows<RPW>(fx, lane));
+    Fy = pair_sum_scaled<GEN>(p, reduce_rows<RPW>(fy, lane));
+    Fz = pair_sum_scaled<GEN>(p, reduce_rows<RPW>(fz, lane));
     const int nb = lane & 3, half = (lane >> 2) & 1;     // lanes 0..3 serve even rows, 4..7 odd rows
 #pragma unroll
     for (int pass = 0; pass < (RPW + 1) / 2; ++pass) {
@@ -226,12 +255,13 @@ __device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevSte
 }
 
 // targets streamed from global memory, one column block ahead (per-step kernel)
-template <int POT, bool GEN, int RPW, bool RS1 = false>
+template <int POT, bool GEN, int RPW>
 __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p, const float* __restrict__ tgt,
                                             const float* xs, const float* ys, const float* zs, int row0, int lane,
                                             float4 (&tv)[RPW], float& Fx, float& Fy, float& Fz) {
     float fx[RPW], fy[RPW], fz[RPW];
     float xi[RPW], yi[RPW], zi[RPW];
+    const PairK k = pair_k(m, p);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = min(row0 + r, m.n - 1);
@@ -249,25 +279,27 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
         const float4 zj = *reinterpret_cast<const float4*>(zs + j);
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
-            pair_quad<POT, GEN, RS1>(m, p, tv[r], noe_weights(p, tv[r]), xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+            pair_quad<POT, GEN>(m, p, k, pair_b<GEN>(m, tv[r]), pair_a<GEN>(m, p, tv[r]), xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) tv[r] = tn[r];
     }
-    reduce_and_chain<RPW>(m, p, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
+    reduce_and_chain<RPW, GEN>(m, p, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
 }
 
-// targets and NOE weights resident in registers for a whole run of equal steps (cluster kernel, compute waves): NB
-// column blocks, fully unrolled.  Returns the butterfly sums of the PAIR terms only: lane l holds the sum for row
-// row0 + (l & 3) (RPW >= 3), row0 + (l & 1) (RPW = 2), row0 (RPW = 1); the chain terms are added by the finishing wave.
+// clamp form with the per-pair constants resident for a whole launch (cluster kernel, compute waves): tv = pair_b in
+// registers, mw_lds = pair_a in LDS; NB column blocks, fully unrolled.  Returns the butterfly sums of the PAIR terms only,
+// WITHOUT the row factor (pair_sum_scaled): lane l holds the sum for row row0 + (l & 3) (RPW >= 3), row0 + (l & 1) (RPW = 2),
+// row0 (RPW = 1); factor and chain terms are added by the finishing wave.
 // NARROW = keep only four pair terms in flight (register budget).
-template <int POT, int RPW, int NB, bool NARROW, bool RS1>
+template <int POT, int RPW, int NB, bool NARROW>
 __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevStep& p, const float4 (&tv)[RPW][NB],
                                                    const float4* mw_lds, const float* xs, const float* ys, const float* zs,
                                                    int row0, int lane, float& Fx, float& Fy, float& Fz) {
-    // mw_lds: this wave's NOE weights of the current run, [RPW * NB][64] float4 in LDS (lane-contiguous: ds_read_b128 at
+    // mw_lds: this wave's pair_a, [RPW * NB][64] float4 in LDS (lane-contiguous: ds_read_b128 at
     // full rate, no VALU slot); keeping them in registers next to the targets overflows the 128 a wave has at RPW x NB = 8
     float fx[RPW], fy[RPW], fz[RPW];
     float xi[RPW], yi[RPW], zi[RPW];
+    const PairK k = pair_k(m, p);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = min(row0 + r, m.n - 1);
@@ -283,7 +315,7 @@ __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevS
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const float4 mw = mw_lds[(r * NB + jb) * 64 + lane];
-            pair_quad<POT, false, RS1>(m, p, tv[r][jb], mw, xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+            pair_quad<POT, false>(m, p, k, tv[r][jb], mw, xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
             if constexpr (NARROW) asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]));   // four pair terms in flight, not 4 RPW NB
         }
     }
