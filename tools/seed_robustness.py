@@ -26,7 +26,7 @@ def key(c):
 
 
 s = Solver(0)
-cids = sorted({os.path.basename(p)[:-len("_upper.npz")] for p in glob.glob(f"{ALL}/*_upper.npz")}, key=key)
+cids = sorted({os.path.basename(p)[:-len("_upper.npz")] for p in glob.glob(f"{ALL}/*_upper.npz") if "standin" not in np.load(p).files}, key=key)
 D = np.zeros((len(cids), len(seeds)))
 for ci, cid in enumerate(cids):
     IF = load(cid)
