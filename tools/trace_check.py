@@ -22,7 +22,8 @@ def bench_line(path):
 def main(argv):
     for stats, bench in zip(argv[0::2], argv[1::2]):
         b = bench_line(bench)
-        name = b["roofline"]["kernel"].split("<")[0].split("::")[-1]
+        # the full instantiation (`k_cluster<3, 4, 2>`): the process also runs other instantiations (config 2's side figure)
+        name = b["roofline"]["kernel"].split("::")[-1]
         rows = [r for r in csv.DictReader(open(stats)) if name in r["Name"]]
         calls = sum(int(r["Calls"]) for r in rows)
         total_us = sum(float(r["TotalDurationNs"]) for r in rows) / 1e3
