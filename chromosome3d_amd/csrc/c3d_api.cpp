@@ -101,6 +101,7 @@ struct c3d_ctx {
     c3d_fire_params fire;
     float gtol = 0.0f;
     int check_every = 250;
+    bool narrow_columns = true;            // option "narrow_columns" 0: every block 4 columns per lane (round 2's layout; measurements)
     bool zero_weight = false;              // some stage has w_all = 0: its steps take the general kernels, no cluster launches
     bool use_graph = true;
     int rpw = 2;
@@ -209,6 +210,15 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
     m.tail_b = (m.tail_c - 2.0f * h.rswitch) * h.rswitch * h.rswitch;
     m.mrs = h.mrswitch; m.nmrs = -h.mrswitch;
     m.inv_rs = 1.0f / h.rswitch; m.nm_rs = -h.mrswitch / h.rswitch;
+    // column layout of the pair loop (c3d_internal.h): lanes of the last 256-column block own wl consecutive columns, up to 8
+    // columns behind it are left over; both follow from n alone, so every launch form sums the same terms in the same order
+    {
+        const int cols_last = c->n - (c->npad - 256);
+        int wl = cols_last / 64, nleft = cols_last - 64 * wl;
+        if (wl == 0 || nleft > 8) { wl = std::min(4, wl + 1); nleft = 0; }
+        if (!c->narrow_columns) { wl = 4; nleft = 0; }
+        m.wl = wl; m.nleft = nleft; m.jl0 = c->npad - 256 + 64 * wl;
+    }
     m.mtail_c = h.masym;
     m.mtail_b = (m.mtail_c - 2.0f * h.mrswitch) * h.mrswitch * h.mrswitch;
     m.k_bond2 = 2.0f * h.k_bond; m.b0 = h.b0;
@@ -761,6 +771,7 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
     }
     if (!strcmp(key, "cluster")) { c->cluster = value < 0 ? -1 : (value != 0); return C3D_OK; }
     if (!strcmp(key, "resident_inject_timeout")) { c->inject_timeout = value != 0; return C3D_OK; }   // test hook
+    if (!strcmp(key, "narrow_columns")) { c->narrow_columns = value != 0; free_replica_buffers(c); drop_graphs(c); return C3D_OK; }
     if (!strcmp(key, "cluster_inject_incomplete")) { c->inject_incomplete = value != 0; return C3D_OK; }   // test hook
     if (!strcmp(key, "cluster_num_xcc")) { c->num_xcc = (int)value; free_replica_buffers(c); return C3D_OK; }   // test hook: pretend a partitioned device
     if (!strcmp(key, "cluster_geometry")) {  // measurement knob: 100 CW + 10 RPW + helpers (0 = planner); before c3d_init_replicas
@@ -1211,7 +1222,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     const c3d::DevModel m = dev_model(c);
     const char* gen = (general_tail(m) || c->zero_weight) ? "true" : "false";
     const char* rs1 = (!general_tail(m) && m.rs == 1.0f) ? "true" : "false";
-    if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d>", m.noe_pot, c->cl_plan.rpw, m.npad / 256);
+    if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %d>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, m.wl);
     else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);
     else if (c->precision == 64) snprintf(buf, sizeof(buf), "c3d::k64_force");
     else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d>", m.noe_pot, gen, m.rpw);

@@ -29,6 +29,7 @@
 // Deck: chromosome3D.pl:1646-1700 (hot MD), :1729-1782 (cooling), :1790-1803 (minimisation).
 #include <hip/hip_ext.h>
 #include <atomic>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -52,7 +53,7 @@ __device__ unsigned long long g_cstamps[64][8];
 #define CSTAMP_C(k) do { } while (0)
 #endif
 
-template <int POT, int RPW, int NB>
+template <int POT, int RPW, int NB, int WL>
 __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const AnnealIO* __restrict__ io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
     const StepRun* __restrict__ runs, const int run0, const int skip0, const int nsteps, const unsigned tag_base,
@@ -68,7 +69,9 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     float* ps = smem + 3 * NPAD;                  // [MAXT][4] per-tile sums of the previous step
     float* fbuf = ps + 4 * MAXT;                  // [3][64] pair sums of this workgroup's rows (compute waves -> H0)
     float* cbuf = fbuf + 3 * 64;                  // [3][64] chain sums of this workgroup's rows (H1..H3 -> H0)
-    float* dump = cbuf + 3 * 64;                  // [4] nobody reads
+    float* lbuf = cbuf + 3 * 64;                  // [3][64] sums over the left-over columns of this workgroup's rows (H1..H3 -> H0)
+    float* lcon = lbuf + 3 * 64;                  // [3 helpers][4 passes][2][64] pair constants (b, a) of the left-over columns: registers are scarce
+    float* dump = lcon + 3 * 4 * 2 * 64;          // [4] nobody reads
     int* s_slot = reinterpret_cast<int*>(dump + 4);
     // dump + 8 ..: [CW][RPW * NB][64] float4, the compute waves' pair_a constants
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,11 +114,30 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int jb = 0; jb < NB; ++jb) {
-                const float4 t = is_compute ? *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * NPAD + 256 * jb + 4 * lane)
-                                            : make_float4(0, 0, 0, 0);
+                float4 t = make_float4(0, 0, 0, 0);
+                if (is_compute) {
+                    const float* trow = tgt + (size_t)min(row0 + r, m.n - 1) * NPAD + 256 * jb;
+                    if (jb < NB - 1 || WL == 4) t = *reinterpret_cast<const float4*>(trow + 4 * lane);
+                    else t = make_float4(trow[WL * lane], WL > 1 ? trow[WL * lane + 1] : 0.0f, WL > 2 ? trow[WL * lane + 2] : 0.0f, 0.0f);   // the last block's lanes own WL columns
+                }
                 tv[r][jb] = pair_b<false>(m, t);
                 if (is_compute) mw[(r * NB + jb) * 64 + lane] = pair_a<false>(m, p0, t);
             }
+    }
+    // chain helpers: pair constants of the left-over columns of "their" rows — pass q of helper `wave` covers rows 8 (wave - 1) +
+    // 8 (NH - 1) q + (lane >> 3) of the workgroup, lane & 7 = the column; at most 4 passes (RW <= 64, two helpers)
+    float* const lc = lcon + (size_t)((wave >= 1 && wave <= 3) ? wave - 1 : 0) * (4 * 2 * 64);
+    if (!is_compute && !is_h0 && wave <= 3 && m.nleft > 0) {
+        for (int q = 0; q < 4; ++q) {
+            const int k = 8 * (wave - 1) + 8 * (NH - 1) * q + (lane >> 3), c = lane & 7;
+            float b = 0.0f, a = 0.0f;
+            if (k < RW && c < m.nleft && wg_row0 + k < m.n) {
+                const float t = tgt[(size_t)(wg_row0 + k) * NPAD + m.jl0 + c];
+                b = t * m.inv_rs;
+                a = t > 0.0f ? m.inv_rs : 0.0f;
+            }
+            lc[(2 * q) * 64 + lane] = b; lc[(2 * q + 1) * 64 + lane] = a;
+        }
     }
     float vcx = 0.0f, vcy = 0.0f, vcz = 0.0f;     // H0: velocity of this lane's row, carried from step to step
     FireState st;
@@ -155,6 +177,13 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const bool stamper = lrep == 0 && part == 0 && is_h0 && lane == 0;
     const bool cstamper = lrep == 0 && part == 0 && cwave == 0 && lane == 0;
 #endif
+    // One step loop PER ROLE (compute wave, H0, chain helper): the waves of a workgroup keep their role for the whole launch, and
+    // written as one loop with role branches inside, every role's registers are live in every other role's code (the compiler
+    // cannot know the branches never mix) — the 32 target registers of the compute waves next to H0's row state and the helpers'
+    // pair terms overflowed the 128 a wave has and were spilled INSIDE the pair loop.  Three loops, same barriers in the same
+    // order: each role's code is allocated on its own.
+    auto role_loop = [&](auto role) {
+    constexpr int ROLE = decltype(role)::value;     // 0 compute wave, 1 H0, 2 chain helper
     int s = 0;
     for (int run = run0;; ++run) {                  // left by the `return` of the last step
       const DevStep p = runs[run].p;
@@ -168,18 +197,18 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         float hx0 = 0.0f, hy0 = 0.0f, hz0 = 0.0f;  // H0: position of this lane's row
         StepScalars sc;
         sc.lam = 1.0f; sc.cmx = sc.cmy = sc.cmz = 0.0f; sc.keep = 0.0f; sc.mix = 0.0f;
-        if (is_compute) {
+        if constexpr (ROLE == 0) {
             // ---- K2: pair terms of RPW rows, butterfly sums, three words per row for H0 ------------------
             if (p.kind != 4) {
                 float Fx, Fy, Fz;
-                tile_pair_sums_reg<POT, RPW, NB, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
+                tile_pair_sums_reg<POT, RPW, NB, WL, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
                 if (lane < RPW) {
                     const int k = cwave * RPW + lane;
                     fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz;
                 }
                 CSTAMP_C(7);                        // compute wave 0: pair loop + reduce done
             }
-        } else if (is_h0) {
+        } else if constexpr (ROLE == 1) {
             // ---- replica sums of the previous step -> scalars of this one (only H0 needs them) -----------
             if (p.kind != 2) { st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0; }
             float4 psum = make_float4(0, 0, 0, 0);
@@ -200,7 +229,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             // this row's position: read now, the barrier below is long
             if (lane < RW && hrow < NPAD) { hx0 = xs[hrow]; hy0 = ys[hrow]; hz0 = zs[hrow]; }
             CSTAMP(1);                              // H0: sums + scalars done
-        } else if (p.kind != 4) {
+        } else if (p.kind != 4) {                  // ROLE 2
             // ---- chain terms: lane = (row, neighbour), 16 rows per helper and pass ------------------------
             for (int cb = 16 * (wave - 1); cb < RW; cb += 16 * (NH - 1)) {
                 const int k = cb + (lane >> 2);
@@ -209,6 +238,19 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 cx = quad_chain_sum(cx); cy = quad_chain_sum(cy); cz = quad_chain_sum(cz);
                 if ((lane & 3) == 0 && k < RW) { cbuf[k] = cx; cbuf[64 + k] = cy; cbuf[128 + k] = cz; }
             }
+            // ---- left-over columns: lane = (row, column), 8 rows per helper and pass, the row's sum in the tree of leftover_terms ----
+            if (m.nleft > 0) {
+                const PairK kk = pair_k(m, p);
+                for (int q = 0; q < 4; ++q) {
+                    const int k = 8 * (wave - 1) + 8 * (NH - 1) * q + (lane >> 3), c = lane & 7;
+                    if (8 * (wave - 1) + 8 * (NH - 1) * q < RW) {           // wave-uniform
+                        const bool active = k < RW && c < m.nleft && wg_row0 + k < m.n;
+                        float lx, ly, lz;
+                        leftover_terms<POT, false>(m, p, kk, xs, ys, zs, min(wg_row0 + k, m.n - 1), c, active, lc[(2 * q) * 64 + lane], lc[(2 * q + 1) * 64 + lane], lx, ly, lz);
+                        if (c == 0 && k < RW) { lbuf[k] = lx; lbuf[64 + k] = ly; lbuf[128 + k] = lz; }
+                    }
+                }
+            }
         }
         __syncthreads();                            // B2: all LDS reads of this step are done; fbuf / cbuf complete
         CSTAMP(2);                                  // H0 past B2 (all compute waves done)
@@ -216,16 +258,18 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         const unsigned tag = tag_base + (unsigned)s + 1u;
         const int base = (((s + 1) & 1) * m.nrep_g + lrep) * units;
 
-        if (is_h0) {
+        if constexpr (ROLE == 1) {
             // ---- row update, lane k <-> row k of the workgroup ------------------------------------------
             float4 q = make_float4(0, 0, 0, 0);
             float xn = 0.0f, yn = 0.0f, zn = 0.0f;
             if (hfin) {
                 float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
                 if (p.kind != 4) {
-                    Fx = pair_sum_scaled<false>(p, fbuf[lane]) + cbuf[lane];
-                    Fy = pair_sum_scaled<false>(p, fbuf[64 + lane]) + cbuf[64 + lane];
-                    Fz = pair_sum_scaled<false>(p, fbuf[128 + lane]) + cbuf[128 + lane];
+                    float sx = fbuf[lane], sy = fbuf[64 + lane], sz = fbuf[128 + lane];
+                    if (m.nleft > 0) { sx += lbuf[lane]; sy += lbuf[64 + lane]; sz += lbuf[128 + lane]; }
+                    Fx = pair_sum_scaled<false>(p, sx) + cbuf[lane];
+                    Fy = pair_sum_scaled<false>(p, sy) + cbuf[64 + lane];
+                    Fz = pair_sum_scaled<false>(p, sz) + cbuf[128 + lane];
                 }
                 float vx0 = vcx, vy0 = vcy, vz0 = vcz;
                 if (p.kind == 3) { vx0 = vy0 = vz0 = 0.0f; }
@@ -311,6 +355,10 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         }
       }
     }
+    };
+    if (is_compute) role_loop(std::integral_constant<int, 0>{});
+    else if (is_h0) role_loop(std::integral_constant<int, 1>{});
+    else role_loop(std::integral_constant<int, 2>{});
 }
 
 #ifdef C3D_STAMPS
@@ -344,17 +392,19 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
         if (fcw && (cw != fcw || rpw != frpw || nh != fnh)) continue;
         if (rw % 8 || rw > 64) continue;
         if (rpw * nb > 8) continue;               // targets in registers: rpw * nb float4 per lane
+        if (m.noe_pot != 3 && (m.wl != 4 || m.nleft != 0)) continue;     // narrow last blocks and left-over columns: shipped potential only
+        if (m.nleft > 0 && (nh != 4 || (rw + 8 * (nh - 1) - 1) / (8 * (nh - 1)) > 4)) continue;       // left-over passes per chain helper (three of them)
         const int P = (m.n + rw - 1) / rw;
         if (per_xcd * P > cus_per_xcd * wpc) continue;
         const int threads = (cw + nh) * 64;
         const int kumax = nb > 2 ? 3 : 2;
         if (P * 2 * rw > threads * kumax) continue;
         // coordinates, sums, row buffers + the compute waves' NOE weights
-        size_t lds = sizeof(float) * (3 * m.npad + 4 * (m.npad / 8) + 6 * 64 + 16) + (size_t)cw * rpw * nb * 64 * 16;
+        size_t lds = sizeof(float) * (3 * m.npad + 4 * (m.npad / 8) + 9 * 64 + 24 * 64 + 16) + (size_t)cw * rpw * nb * 64 * 16;
         if (wpc == 1) { if (lds < 84 * 1024) lds = 84 * 1024; }    // more than half of a CU's 160 KB: one workgroup per CU
         else if (lds > 78 * 1024 || threads > 512) continue;        // two per CU must fit
         const int wps = (cw * wpc + 3) / 4;       // compute waves per SIMD; a lone wave issues at ~0.6 of the multi-wave rate
-        const double valu = (wps == 1 ? 1.6 : (wps == 2 ? 1.15 : 1.0)) * wps * (rpw * nb * 60.0 + 60.0);
+        const double valu = (wps == 1 ? 1.6 : (wps == 2 ? 1.15 : 1.0)) * wps * (rpw * (4 * (nb - 1) + m.wl) * 15.0 + 60.0);
         const double serial = 200.0 + (P > 1 ? 570.0 : 0.0);
         // one workgroup per CU: the serial tail of a step follows its pair loop; two per CU: the tails hide behind the
         // other workgroup's loop where there is one
@@ -371,7 +421,7 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
 
 size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl) { return (size_t)2 * m.nrep_g * pl.parts * pl.units * 16; }
 
-template <int POT, int RPW, int NB>
+template <int POT, int RPW, int NB, int WL>
 static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
                              const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                              hipStream_t s) {
@@ -380,15 +430,15 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
     static std::atomic<bool> attr_set[64];
     const int dev = pl.device & 63;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, WL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev].store(true, std::memory_order_release);
     }
     if (pl.t0 && pl.t1)
-        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
+        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, WL>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
                               reinterpret_cast<u32x4*>(rec), runs, run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, m, fp);
     else
-        hipLaunchKernelGGL((k_cluster<POT, RPW, NB>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
+        hipLaunchKernelGGL((k_cluster<POT, RPW, NB, WL>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
                            run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, m, fp);
     return hipGetLastError();
 }
@@ -397,7 +447,15 @@ static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const Clust
                                const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                                hipStream_t s) {
 #define C3D_CL(R, B)                                                                                                    \
-    if (pl.rpw == R && m.npad == 256 * B) return cluster_go<POT, R, B>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s)
+    if (pl.rpw == R && m.npad == 256 * B) {                                                                             \
+        if (m.wl == 4) return cluster_go<POT, R, B, 4>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
+        if constexpr (POT == 3) {   /* narrower last blocks: the shipped potential only (cluster_plan refuses the others) */      \
+            if (m.wl == 3) return cluster_go<POT, R, B, 3>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
+            if (m.wl == 2) return cluster_go<POT, R, B, 2>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
+            if (m.wl == 1) return cluster_go<POT, R, B, 1>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
+        }                                                                                                               \
+        return hipErrorInvalidValue;                                                                                    \
+    }
     C3D_CL(1, 1); C3D_CL(1, 2); C3D_CL(1, 3); C3D_CL(1, 4);
     C3D_CL(2, 1); C3D_CL(2, 2); C3D_CL(2, 3); C3D_CL(2, 4);
     C3D_CL(3, 1); C3D_CL(3, 2);

@@ -28,6 +28,11 @@ struct DevModel {
     float mrs, mtail_c, mtail_b;   // noe_pot 3, lower side: dE/dD = mtail_c - mtail_b / D^2  (D = t - d > mrs)
     float nmrs;                    // -mrs
     float inv_rs, nm_rs;           // 1 / rs, -mrs / rs: the clamp form works on (d - t) / (rs d), see pair_term
+    // Column layout of the pair loop (c3d_step_core.h): blocks of 256 columns, lane l owns 4 consecutive ones — except in the LAST
+    // block, where it owns wl (1..4) consecutive ones: column 256 (nb - 1) + wl l + c.  Up to 8 columns beyond the last block
+    // (jl0 .. jl0 + nleft - 1 = n - 1) are "left over": their pair terms are evaluated eight to a row in a separate short pass
+    // and summed in their own fixed tree.  n = 455: 256 + 64 x 3 + 7 -> 7 column slots per row instead of 8.
+    int wl, nleft, jl0;
     float k_bond2, b0;             // 2*k_bond
     float k_ang2, a0;              // 2*k_ang
     float acc;                     // kAccel / mass

@@ -105,12 +105,35 @@ __device__ __forceinline__ float noe_grad(float delta, const DevModel& m) {
 // One "column block" = 256 columns: lane l owns columns 256*jb + 4l .. 4l+3, so every target
 // load is a 16-byte global_load_dwordx4 and every coordinate read a ds_read_b128 (dword loads
 // are address-rate bound in the texture path: 1 pair per load instruction-lane starves the VALU).
+// first column of lane `lane` in block jb, and how many consecutive columns it owns there (4; wl in the last block)
+__device__ __forceinline__ int block_col0(const DevModel& m, int jb, int lane, int& width) {
+    const bool last = 256 * (jb + 1) >= m.npad;
+    width = last ? m.wl : 4;
+    return 256 * jb + width * lane;
+}
 template <int RPW>
 __device__ __forceinline__ void tile_prefetch(const DevModel& m, const float* __restrict__ tgt, int row0, int lane,
                                               int jb, float4 (&tv)[RPW]) {
+    int width;
+    const int j = block_col0(m, jb, lane, width);
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
-        tv[r] = *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 256 * jb + 4 * lane);
+    for (int r = 0; r < RPW; ++r) {
+        const float* t = tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + j;
+        if (width == 4) tv[r] = *reinterpret_cast<const float4*>(t);
+        else tv[r] = make_float4(t[0], width > 1 ? t[1] : 0.0f, width > 2 ? t[2] : 0.0f, 0.0f);   // 4-byte aligned only
+    }
+}
+// coordinates of a lane's columns in block jb (a component beyond the lane's width is never used)
+__device__ __forceinline__ void block_coords(const DevModel& m, const float* xs, const float* ys, const float* zs, int jb, int lane,
+                                             int& width, float4& xj, float4& yj, float4& zj) {
+    const int j = block_col0(m, jb, lane, width);
+    if (width == 4) {
+        xj = *reinterpret_cast<const float4*>(xs + j); yj = *reinterpret_cast<const float4*>(ys + j); zj = *reinterpret_cast<const float4*>(zs + j);
+    } else {
+        xj = make_float4(xs[j], width > 1 ? xs[j + 1] : 0.0f, width > 2 ? xs[j + 2] : 0.0f, 0.0f);
+        yj = make_float4(ys[j], width > 1 ? ys[j + 1] : 0.0f, width > 2 ? ys[j + 2] : 0.0f, 0.0f);
+        zj = make_float4(zs[j], width > 1 ? zs[j + 1] : 0.0f, width > 2 ? zs[j + 2] : 0.0f, 0.0f);
+    }
 }
 
 // One pair term.  F_i += c * (x_i - x_j) with c = -(dE/dd)/d.  Written to minimise VALU issue slots: the solver is bound by
@@ -194,6 +217,33 @@ __device__ __forceinline__ void pair_quad(const DevModel& m, const DevStep& p, c
     pair_term<POT, GEN>(m, p, k, tb.z, ta.z, xi - xj.z, yi - yj.z, zi - zj.z, fx, fy, fz);
     pair_term<POT, GEN>(m, p, k, tb.w, ta.w, xi - xj.w, yi - yj.w, zi - zj.w, fx, fy, fz);
 }
+// the same for a lane that owns only `width` (1..3) columns of the block (wave-uniform): the pair terms of the columns it
+// does not own are not formed at all
+template <int POT, bool GEN>
+__device__ __forceinline__ void pair_quad_w(const DevModel& m, const DevStep& p, const PairK& k, int width, const float4 tb, const float4 ta,
+                                            float xi, float yi, float zi, const float4 xj, const float4 yj, const float4 zj, float& fx,
+                                            float& fy, float& fz) {
+    pair_term<POT, GEN>(m, p, k, tb.x, ta.x, xi - xj.x, yi - yj.x, zi - zj.x, fx, fy, fz);
+    if (width > 1) pair_term<POT, GEN>(m, p, k, tb.y, ta.y, xi - xj.y, yi - yj.y, zi - zj.y, fx, fy, fz);
+    if (width > 2) pair_term<POT, GEN>(m, p, k, tb.z, ta.z, xi - xj.z, yi - yj.z, zi - zj.z, fx, fy, fz);
+}
+// Left-over columns (DevModel::nleft <= 8): row `row`'s pair term against column jl0 + c, one (row, c) per lane, eight lanes to
+// a row; returns in the FIRST lane of the eight the sum ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7)) of the row's terms
+// (a lane without a column contributes an exact 0).  `tgt` = the row's target row in global memory or nullptr when the
+// caller passes the pair constants itself (tb, ta: cluster kernel, loaded once per launch).
+template <int POT, bool GEN>
+__device__ __forceinline__ void leftover_terms(const DevModel& m, const DevStep& p, const PairK& k, const float* xs, const float* ys,
+                                               const float* zs, int row, int c, bool active, float tb, float ta, float& lx, float& ly,
+                                               float& lz) {
+    lx = ly = lz = 0.0f;
+    if (active) {
+        const int j = m.jl0 + c;
+        pair_term<POT, GEN>(m, p, k, tb, ta, xs[row] - xs[j], ys[row] - ys[j], zs[row] - zs[j], lx, ly, lz);
+    }
+    lx += dpp_mov<0xB1>(lx); ly += dpp_mov<0xB1>(ly); lz += dpp_mov<0xB1>(lz);
+    lx += dpp_mov<0x4E>(lx); ly += dpp_mov<0x4E>(ly); lz += dpp_mov<0x4E>(lz);
+    lx += dpp_mov<0x12C>(lx); ly += dpp_mov<0x12C>(ly); lz += dpp_mov<0x12C>(lz);     // row_ror:12 = lane + 4
+}
 
 // One chain term: neighbour nb (0..3 = offsets -2,-1,+1,+2) of `row`: pseudo-bond (i,i+-1), pseudo-angle (i,i+-2) and the
 // repel take-back for |i-j| < rep_sep (the pair loop applies the repel term to every column).  `active` = the lane
@@ -230,13 +280,38 @@ __device__ __forceinline__ float quad_chain_sum(float c) {
 // Here (per-step kernel, forces hook): rows row0 .. row0+RPW-1 of one wave.  Chain terms: neighbour nb of row i is
 // evaluated by lane 4 (i & 1) + nb, two rows per pass; the quad sums are then brought to lane r = i - row0, the row's
 // finisher (lanes 0 .. RPW-1).
-template <int RPW, bool GEN>
-__device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevStep& p, const float* xs, const float* ys,
-                                                 const float* zs, int row0, int lane, float (&fx)[RPW], float (&fy)[RPW],
-                                                 float (&fz)[RPW], float& Fx, float& Fy, float& Fz) {
-    Fx = pair_sum_scaled<GEN>(p, reduce_rows<RPW>(fx, lane));
-    Fy = pair_sum_scaled<GEN>(p, reduce_rows<RPW>(fy, lane));
-    Fz = pair_sum_scaled<GEN>(p, reduce_rows<RPW>(fz, lane));
+template <int POT, int RPW, bool GEN>
+__device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevStep& p, const float* __restrict__ tgt, const float* xs,
+                                                 const float* ys, const float* zs, int row0, int lane, float (&fx)[RPW],
+                                                 float (&fy)[RPW], float (&fz)[RPW], float& Fx, float& Fy, float& Fz) {
+    Fx = reduce_rows<RPW>(fx, lane);
+    Fy = reduce_rows<RPW>(fy, lane);
+    Fz = reduce_rows<RPW>(fz, lane);
+    if (m.nleft > 0) {
+        // left-over columns of this wave's rows: lane 8 r + c evaluates (row r, column jl0 + c); the row's sum comes out in lane
+        // 8 r and goes to the row's finisher, lane r
+        const int r = lane >> 3, c = lane & 7;
+        const int row = row0 + r;
+        const bool active = r < RPW && c < m.nleft && row < m.n;
+        float tb = 0.0f, ta = 0.0f;
+        if (active) {
+            const float t = tgt[(size_t)row * m.npad + m.jl0 + c];
+            tb = GEN ? t : t * m.inv_rs;
+            ta = t > 0.0f ? (GEN ? p.w_noe2n : m.inv_rs) : 0.0f;
+        }
+        float lx, ly, lz;
+        leftover_terms<POT, GEN>(m, p, pair_k(m, p), xs, ys, zs, min(row, m.n - 1), c, active, tb, ta, lx, ly, lz);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const float ax = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lx), 8 * q));
+            const float ay = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ly), 8 * q));
+            const float az = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lz), 8 * q));
+            if (lane == q) { Fx += ax; Fy += ay; Fz += az; }
+        }
+    }
+    Fx = pair_sum_scaled<GEN>(p, Fx);
+    Fy = pair_sum_scaled<GEN>(p, Fy);
+    Fz = pair_sum_scaled<GEN>(p, Fz);
     const int nb = lane & 3, half = (lane >> 2) & 1;     // lanes 0..3 serve even rows, 4..7 odd rows
 #pragma unroll
     for (int pass = 0; pass < (RPW + 1) / 2; ++pass) {
@@ -273,17 +348,22 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
         float4 tn[RPW];
         const int jn = jb + 1 < nblk ? jb + 1 : jb;     // last block re-reads itself (in bounds)
         tile_prefetch<RPW>(m, tgt, row0, lane, jn, tn);  // next block in flight while this one computes
-        const int j = 256 * jb + 4 * lane;
-        const float4 xj = *reinterpret_cast<const float4*>(xs + j);
-        const float4 yj = *reinterpret_cast<const float4*>(ys + j);
-        const float4 zj = *reinterpret_cast<const float4*>(zs + j);
+        int width;
+        float4 xj, yj, zj;
+        block_coords(m, xs, ys, zs, jb, lane, width, xj, yj, zj);
+        if (width == 4) {
 #pragma unroll
-        for (int r = 0; r < RPW; ++r)
-            pair_quad<POT, GEN>(m, p, k, pair_b<GEN>(m, tv[r]), pair_a<GEN>(m, p, tv[r]), xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+            for (int r = 0; r < RPW; ++r)
+                pair_quad<POT, GEN>(m, p, k, pair_b<GEN>(m, tv[r]), pair_a<GEN>(m, p, tv[r]), xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                pair_quad_w<POT, GEN>(m, p, k, width, pair_b<GEN>(m, tv[r]), pair_a<GEN>(m, p, tv[r]), xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+        }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) tv[r] = tn[r];
     }
-    reduce_and_chain<RPW, GEN>(m, p, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
+    reduce_and_chain<POT, RPW, GEN>(m, p, tgt, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
 }
 
 // clamp form with the per-pair constants resident for a whole launch (cluster kernel, compute waves): tv = pair_b in
@@ -291,7 +371,7 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
 // WITHOUT the row factor (pair_sum_scaled): lane l holds the sum for row row0 + (l & 3) (RPW >= 3), row0 + (l & 1) (RPW = 2),
 // row0 (RPW = 1); factor and chain terms are added by the finishing wave.
 // NARROW = keep only four pair terms in flight (register budget).
-template <int POT, int RPW, int NB, bool NARROW>
+template <int POT, int RPW, int NB, int WL, bool NARROW>
 __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevStep& p, const float4 (&tv)[RPW][NB],
                                                    const float4* mw_lds, const float* xs, const float* ys, const float* zs,
                                                    int row0, int lane, float& Fx, float& Fy, float& Fz) {
@@ -308,14 +388,22 @@ __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevS
     }
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb) {
-        const int j = 256 * jb + 4 * lane;
-        const float4 xj = *reinterpret_cast<const float4*>(xs + j);
-        const float4 yj = *reinterpret_cast<const float4*>(ys + j);
-        const float4 zj = *reinterpret_cast<const float4*>(zs + j);
+        constexpr int W4 = 4;
+        const int width = jb == NB - 1 ? WL : W4;           // compile-time after unrolling: the last block's lanes own WL columns
+        const int j = 256 * jb + width * lane;
+        float4 xj, yj, zj;
+        if (width == 4) {
+            xj = *reinterpret_cast<const float4*>(xs + j); yj = *reinterpret_cast<const float4*>(ys + j); zj = *reinterpret_cast<const float4*>(zs + j);
+        } else {
+            xj = make_float4(xs[j], width > 1 ? xs[j + 1] : 0.0f, width > 2 ? xs[j + 2] : 0.0f, 0.0f);
+            yj = make_float4(ys[j], width > 1 ? ys[j + 1] : 0.0f, width > 2 ? ys[j + 2] : 0.0f, 0.0f);
+            zj = make_float4(zs[j], width > 1 ? zs[j + 1] : 0.0f, width > 2 ? zs[j + 2] : 0.0f, 0.0f);
+        }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const float4 mw = mw_lds[(r * NB + jb) * 64 + lane];
-            pair_quad<POT, false>(m, p, k, tv[r][jb], mw, xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+            if (width == 4) pair_quad<POT, false>(m, p, k, tv[r][jb], mw, xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
+            else pair_quad_w<POT, false>(m, p, k, width, tv[r][jb], mw, xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
             if constexpr (NARROW) asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]));   // four pair terms in flight, not 4 RPW NB
         }
     }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(1024) void k_loop(const float* __restrict__ in, flo
         if constexpr (MODE >= 1) __syncthreads();
         if (is_compute) {
             float Fx, Fy, Fz;
-            tile_pair_sums_reg<3, RPW, NB, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
+            tile_pair_sums_reg<3, RPW, NB, 4, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
             if (lane < RPW) { const int k = cwave * RPW + lane; fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz; }
             acc += Fx;
         }
@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
     float *in, *out; CK(hipMalloc(&in, 4096)); CK(hipMalloc(&out, 4 * 1024 * prop.multiProcessorCount * 2));
     float h[1024]; for (int i = 0; i < 1024; ++i) h[i] = 0.37f * (i % 29) - 4.0f + 0.01f * i;
     CK(hipMemcpy(in, h, 4096, hipMemcpyHostToDevice));
-    DevModel m{}; m.n = 455; m.npad = 512; m.nmrs = -4.0f; m.mrs = 4.0f; m.rs = 0.5f; m.inv_rs = 2.0f; m.nm_rs = -8.0f;
+    DevModel m{}; m.n = 455; m.npad = 512; m.nmrs = -4.0f; m.mrs = 4.0f; m.rs = 0.5f; m.inv_rs = 2.0f; m.nm_rs = -8.0f; m.wl = 4;
     DevStep p{}; p.kind = 1; p.w_noe2n = -20.0f; p.inv_rep_r2 = 1.0f / 21.0f; p.w_rep4r2 = 4.0f * 21.0f; p.w_rs = -10.0f; p.kq = -8.4f;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int lds = (wgs_per_cu > 1 ? 60 : 100) * 1024, iters = 2000;

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(1024) void k_loop(const float* __restrict__ in, flo
         __syncthreads();
         if (is_compute) {
             float Fx, Fy, Fz;
-            if constexpr (FORM == 0 || FORM == 10) tile_pair_sums_reg<3, RPW, NB, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);   // the product's form
+            if constexpr (FORM == 0) tile_pair_sums_reg<3, RPW, NB, 4, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);   // the product's form
+            else if constexpr (FORM == 10) tile_pair_sums_reg<3, RPW, NB, 3, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);   // last block 3 columns per lane (N = 455)
             else tile_s<RPW, NB>(k2.nm, k2.kq, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
             if (lane < RPW) { const int k = cwave * RPW + lane; fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz; }
             acc += Fx;
@@ -111,14 +112,14 @@ int main() {
     float *in, *out; CK(hipMalloc(&in, 4096)); CK(hipMalloc(&out, 4 * 1024 * prop.multiProcessorCount * 2));
     float h[1024]; for (int i = 0; i < 1024; ++i) h[i] = 0.37f * (i % 29) - 4.0f + 0.01f * i;
     CK(hipMemcpy(in, h, 4096, hipMemcpyHostToDevice));
-    DevModel m{}; m.n = 455; m.npad = 512; m.nmrs = -4.0f; m.mrs = 4.0f; m.rs = 0.5f; m.inv_rs = 2.0f; m.nm_rs = -8.0f;
+    DevModel m{}; m.n = 455; m.npad = 512; m.nmrs = -4.0f; m.mrs = 4.0f; m.rs = 0.5f; m.inv_rs = 2.0f; m.nm_rs = -8.0f; m.wl = 4;
     DevStep p{}; p.kind = 1; p.w_noe2n = -20.0f; p.inv_rep_r2 = 1.0f / 21.0f; p.w_rep4r2 = 4.0f * 21.0f; p.w_rs = -10.0f; p.kq = -8.4f;
     K2 k2{-8.0f, 0.3f};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int lds = 100 * 1024, iters = 2000, grid = prop.multiProcessorCount;
     struct { int form, rpw, cw, nh; const char* what; } cases[] = {
         {0, 4, 12, 4, "product form (c3d_step_core.h, 15 instr)   12 x 4 rows + 4 idle"},
-        {10, 4, 12, 4, "product form again                         12 x 4 rows + 4 idle"},
+        {10, 4, 12, 4, "product form, 7 column slots (N = 455)     12 x 4 rows + 4 idle"},
         {1, 4, 12, 4, "F1 scaled form (15 instr)                  12 x 4 rows + 4 idle"},
         {0, 3, 16, 0, "product form                               16 x 3 rows"},
         {1, 3, 16, 0, "F1 scaled form                             16 x 3 rows"},
