@@ -99,9 +99,11 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const int hrow = wg_row0 + lane;              // H0: the row of this lane
     const bool hfin = is_h0 && lane < RW && hrow < m.n;
 #define C3D_HROW_INDEX const size_t ix = roff + hrow, iy = ix + NPAD, iz = iy + NPAD   /* formed where used: H0 only */
-    const int units = P * 2 * RW;
+    // units of one (parity, replica): row r at r, tile t at NPAD + 2 t and + 1; only real rows and tiles travel
+    constexpr int rec_stride = NPAD + NPAD / 4;
+    const int units = m.n + 2 * m.ntiles;
     const int ku = (units + nthreads - 1) / nthreads;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, (int)(sizeof(u32x4) * 2 * m.nrep_g * units), 0x00020000);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, (int)(sizeof(u32x4) * 2 * m.nrep_g * rec_stride), 0x00020000);
 
     // ---- prologue: everything that stays for the whole launch --------------------------------------
     // per-pair constants of the clamp form (c3d_step_core.h: pair_b = target / rswitch in registers, pair_a = 1 / rswitch where
@@ -154,23 +156,21 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     }
     // gather bookkeeping: unit u = tid + nthreads k is unit (u & 1) of row (u >> 1) % RW of part (u >> 1) / RW:
     // unit 0 = {x, y}, unit 1 = {z, s}; s = word (row & 7) of the tile's four sums where row & 7 < 4
-    int gda[KUMAX], gdb[KUMAX];                   // float offsets into smem
+    int gsrc[KUMAX], gda[KUMAX], gdb[KUMAX], gdc[KUMAX];      // unit index inside the record; float offsets into smem
     const int dump_off = (int)(dump - smem);
 #pragma unroll
     for (int k = 0; k < KUMAX; ++k) {
-        const int u = tid + nthreads * k;
-        int da = dump_off, db = dump_off;
-        if (u < units) {
-            const int r = u >> 1;                 // part * RW + row in part = global row
-            if (r < NPAD) {
-                if ((u & 1) == 0) { da = r; db = NPAD + r; }
-                else {
-                    da = 2 * NPAD + r;
-                    if ((r & 7) < 4) db = 3 * NPAD + 4 * (r >> 3) + (r & 7);
-                }
-            }
+        const int u = min(tid + nthreads * k, units - 1);
+        int src, da, db = dump_off, dc = dump_off;
+        if (u < m.n) { src = u; da = u; db = NPAD + u; dc = 2 * NPAD + u; }
+        else {
+            const int j = u - m.n, t = j >> 1;
+            src = NPAD + j;
+            if ((j & 1) == 0) { da = 3 * NPAD + 4 * t; db = da + 1; dc = da + 2; }
+            else da = 3 * NPAD + 4 * t + 3;
         }
-        gda[k] = da; gdb[k] = db;
+        if (tid + nthreads * k >= units) da = db = dc = dump_off;
+        gsrc[k] = src; gda[k] = da; gdb[k] = db; gdc[k] = dc;
     }
 
 #ifdef C3D_STAMPS
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         CSTAMP(2);                                  // H0 past B2 (all compute waves done)
         const bool last = s + 1 == nsteps;
         const unsigned tag = tag_base + (unsigned)s + 1u;
-        const int base = (((s + 1) & 1) * m.nrep_g + lrep) * units;
+        const int base = (((s + 1) & 1) * m.nrep_g + lrep) * rec_stride;
 
         if constexpr (ROLE == 1) {
             // ---- row update, lane k <-> row k of the workgroup ------------------------------------------
@@ -275,8 +275,13 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 if (p.kind == 3) { vx0 = vy0 = vz0 = 0.0f; }
                 else if (p.kind == 4) { C3D_HROW_INDEX; const float* vinit = io->vinit; vx0 = vinit[ix]; vy0 = vinit[iy]; vz0 = vinit[iz]; }
                 finish_row(m, p, fp, sc, st, Fx, Fy, Fz, hx0, hy0, hz0, vx0, vy0, vz0, xn, yn, zn, vcx, vcy, vcz, q);
+                if (!last && !solo) {               // the row's new position leaves at once; the tile sums follow below
+                    u32x4 o;
+                    o.x = tag; o.y = __float_as_uint(xn); o.z = __float_as_uint(yn); o.w = __float_as_uint(zn);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (base + hrow) * 16, 0, 0);     // plain: the line stays in this XCD's L2
+                }
             } else {
-                xn = hx0; yn = hy0; zn = hz0;       // padding row: republish as is
+                xn = hx0; yn = hy0; zn = hz0;       // padding row (one-workgroup replicas write it back as it is)
             }
             // tile sums, the tree of tile_sum8 over eight consecutive lanes: lane 8 t ends with tile t's four sums
             float4 t = q;
@@ -304,16 +309,13 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 // one workgroup owns the replica: new positions and tile sums go straight back into LDS
                 if (lane < RW && hrow < NPAD) { xs[hrow] = xn; ys[hrow] = yn; zs[hrow] = zn; }
                 if ((lane & 7) == 0 && lane < RW) reinterpret_cast<float4*>(ps)[lane >> 3] = t;
-            } else if (lane < RW) {
-                // publish: word (lane & 7) of the tile's sums rides with rows 8 t .. 8 t + 3
-                const float s1 = dpp_mov<0x111>(t.y), s2 = dpp_mov<0x112>(t.z), s3 = dpp_mov<0x113>(t.w);   // row_shr:1..3
-                const int c = lane & 7;
-                const float sw = c == 0 ? t.x : (c == 1 ? s1 : (c == 2 ? s2 : (c == 3 ? s3 : 0.0f)));
+            } else if ((lane & 7) == 0 && lane < RW && ((wg_row0 + lane) >> 3) < m.ntiles) {
+                // publish the tile's four sums (lane 8 t holds them)
                 u32x4 o0, o1;
-                o0.x = tag; o0.y = __float_as_uint(xn); o0.z = tag; o0.w = __float_as_uint(yn);
-                o1.x = tag; o1.y = __float_as_uint(zn); o1.z = tag; o1.w = __float_as_uint(sw);
-                const int u0 = base + 2 * (part * RW + lane);
-                __builtin_amdgcn_raw_buffer_store_b128(o0, rsrc, u0 * 16, 0, 0);          // plain: the line stays in this XCD's L2
+                o0.x = tag; o0.y = __float_as_uint(t.x); o0.z = __float_as_uint(t.y); o0.w = __float_as_uint(t.z);
+                o1.x = tag; o1.y = __float_as_uint(t.w); o1.z = 0u; o1.w = 0u;
+                const int u0 = base + NPAD + 2 * ((wg_row0 + lane) >> 3);
+                __builtin_amdgcn_raw_buffer_store_b128(o0, rsrc, u0 * 16, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, rsrc, (u0 + 1) * 16, 0, 0);
             }
         }
@@ -332,13 +334,10 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 asm volatile("" ::: "memory");     // the loads below must be re-issued on every sweep
 #pragma unroll
                 for (int k = 0; k < KUMAX; ++k)
-                    if (k < ku) {
-                        const int u = min(tid + nthreads * k, units - 1);
-                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + u) * 16, 0, 16);   // aux 16 = sc1: bypass L1
-                    }
+                    if (k < ku) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + gsrc[k]) * 16, 0, 16);   // aux 16 = sc1: bypass L1
 #pragma unroll
                 for (int k = 0; k < KUMAX; ++k)
-                    if (k < ku) ok &= v[k].x == tag && v[k].z == tag;
+                    if (k < ku) ok &= v[k].x == tag;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             CSTAMP(5);                              // H0's gather complete
 #pragma unroll
             for (int k = 0; k < KUMAX; ++k)
-                if (k < ku) { smem[gda[k]] = __uint_as_float(v[k].y); smem[gdb[k]] = __uint_as_float(v[k].w); }
+                if (k < ku) { smem[gda[k]] = __uint_as_float(v[k].y); smem[gdb[k]] = __uint_as_float(v[k].z); smem[gdc[k]] = __uint_as_float(v[k].w); }
         }
       }
     }
@@ -398,7 +397,7 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
         if (per_xcd * P > cus_per_xcd * wpc) continue;
         const int threads = (cw + nh) * 64;
         const int kumax = nb > 2 ? 3 : 2;
-        if (P * 2 * rw > threads * kumax) continue;
+        if (m.n + 2 * ((m.n + 7) / 8) > threads * kumax) continue;      // gather: units per thread
         // coordinates, sums, row buffers + the compute waves' NOE weights
         size_t lds = sizeof(float) * (3 * m.npad + 4 * (m.npad / 8) + 9 * 64 + 24 * 64 + 16) + (size_t)cw * rpw * nb * 64 * 16;
         if (wpc == 1) { if (lds < 84 * 1024) lds = 84 * 1024; }    // more than half of a CU's 160 KB: one workgroup per CU
@@ -419,7 +418,8 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
     return found;
 }
 
-size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl) { return (size_t)2 * m.nrep_g * pl.parts * pl.units * 16; }
+// two parities x replicas x (one 16-byte unit per row + two per 8-row tile)
+size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl) { (void)pl; return (size_t)2 * m.nrep_g * (m.npad + m.npad / 4) * 16; }
 
 template <int POT, int RPW, int NB, int WL>
 static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,

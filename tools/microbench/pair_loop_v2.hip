@@ -84,6 +84,7 @@ __global__ __launch_bounds__(1024) void k_loop(const float* __restrict__ in, flo
             float Fx, Fy, Fz;
             if constexpr (FORM == 0) tile_pair_sums_reg<3, RPW, NB, 4, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);   // the product's form
             else if constexpr (FORM == 10) tile_pair_sums_reg<3, RPW, NB, 3, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);   // last block 3 columns per lane (N = 455)
+            else if constexpr (FORM == 11) tile_pair_sums_reg<3, RPW, NB, 3, false>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);  // the same, scheduler unconstrained
             else tile_s<RPW, NB>(k2.nm, k2.kq, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
             if (lane < RPW) { const int k = cwave * RPW + lane; fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz; }
             acc += Fx;
@@ -120,6 +121,7 @@ int main() {
     struct { int form, rpw, cw, nh; const char* what; } cases[] = {
         {0, 4, 12, 4, "product form (c3d_step_core.h, 15 instr)   12 x 4 rows + 4 idle"},
         {10, 4, 12, 4, "product form, 7 column slots (N = 455)     12 x 4 rows + 4 idle"},
+        {11, 4, 12, 4, "product form, 7 slots, not NARROW          12 x 4 rows + 4 idle"},
         {1, 4, 12, 4, "F1 scaled form (15 instr)                  12 x 4 rows + 4 idle"},
         {0, 3, 16, 0, "product form                               16 x 3 rows"},
         {1, 3, 16, 0, "F1 scaled form                             16 x 3 rows"},
@@ -132,6 +134,7 @@ int main() {
         float ms = 0;
         if (c.form == 0 && c.rpw == 4) ms = run<0, 4>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
         else if (c.form == 10 && c.rpw == 4) ms = run<10, 4>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
+        else if (c.form == 11 && c.rpw == 4) ms = run<11, 4>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
         else if (c.form == 1 && c.rpw == 4) ms = run<1, 4>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
         else if (c.form == 0 && c.rpw == 3) ms = run<0, 3>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
         else if (c.form == 1 && c.rpw == 3) ms = run<1, 3>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
