@@ -130,13 +130,15 @@ struct c3d_ctx {
     long steps_done = 0;
     std::map<std::tuple<long, int, int, int>, hipGraphExec_t> graphs;
 
-    c3d::AnnealIO* d_io = nullptr;         // [2] pointer blocks of the multi-step launch, by parity
     bool inject_timeout = false;           // test hook: pretend the next resident launch timed out
     int resident_fallbacks = 0;            // resident launches abandoned for the per-step path (see run_resident)
     int resident_skip = 0;                 // ranges left to run step by step before a multi-step launch is tried again
     int resident_backoff = 0;              // doubles with every abandoned launch, back to 0 after a good one
     int num_cus = 0, num_xcc = 0;
     int cluster_geom = 0;                  // measurement knob: 100 CW + 10 RPW + helpers forces that cluster geometry (0 = planner's choice)
+    bool inject_misplaced = false;         // test hook: workgroup 0 of the next cluster launch reports a wrong XCD
+    bool static_place = true;              // cluster launches number the workgroups of an XCD as blockIdx / 8 (verified in the kernel)
+    int placement_mismatches = 0;
     bool inject_incomplete = false;        // test hook: the next cluster launch expects one workgroup more than will ever report
     int cluster_incomplete = 0;            // cluster launches that ended without the completion mark (and were re-run step by step)
 
@@ -185,7 +187,7 @@ void free_replica_buffers(c3d_ctx* c) {
     for (int k = 0; k < 2; ++k) {
         dev_free(c->buf.X[k]); dev_free(c->buf.V[k]); dev_free(c->buf.P[k]); dev_free(c->buf.S[k]);
     }
-    dev_free(c->d_io); dev_free(c->d_crec);
+    dev_free(c->d_crec);
     c->crec_bytes = 0; c->cl_ok = false;
     dev_free(c->buf.Vinit); dev_free(c->buf.E); dev_free(c->d_feval);
     dev_free(c->d_sym_scratch); dev_free(c->d_sym_tiles);
@@ -364,6 +366,8 @@ bool cluster_ok(c3d_ctx* c) {
 // replica's workgroups were not all resident, e.g. another process fills the GPU) the caller runs the same ops on
 // the per-step path; the next `resident_backoff` ranges go there too before a multi-step launch is tried again.
 bool launch_was_abandoned(c3d_ctx* c, unsigned done_mark) {
+    // a workgroup found itself on another XCD than blockIdx % 8: from now on this context claims slots from per-XCD counters
+    if (c->h_tmo[2]) { c->h_tmo[2] = 0; c->static_place = false; ++c->placement_mismatches; }
     // complete = the last of the launch's replicas x parts workgroups wrote the mark (c3d_cluster.hip); a launch that
     // neither timed out nor completed left some (replica, part) unclaimed: same treatment, counted separately
     const bool complete = c->h_tmo[1] == done_mark;
@@ -407,7 +411,10 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     c3d::ClusterPlan pl = c->cl_plan;
     if (c->inject_incomplete) { ++pl.expected; c->inject_incomplete = false; }
     if (c->kernel_timing) { pl.t0 = c->kev0; pl.t1 = c->kev1; }
-    hipError_t e = c3d::launch_cluster(m, dev_fire(c), pl, c->d_io + c->parity, c->buf.tgt, c->d_crec, c->d_prog,
+    pl.static_place = c->static_place ? (c->inject_misplaced ? 2 : 1) : 0;
+    c->inject_misplaced = false;
+    c->h_tmo[2] = 0;
+    hipError_t e = c3d::launch_cluster(m, dev_fire(c), pl, c3d::anneal_io(c->buf, c->parity), c->buf.tgt, c->d_crec, c->d_prog,
                                        c->op_run[c->pc], c->op_skip[c->pc], (int)nops, seq << 20, c->h_tmo_dev,
                                        c->d_claim + c3d_ctx::kClaimWords * seq, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("cluster launch: ") + hipGetErrorString(e));
@@ -772,6 +779,7 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
     if (!strcmp(key, "cluster")) { c->cluster = value < 0 ? -1 : (value != 0); return C3D_OK; }
     if (!strcmp(key, "resident_inject_timeout")) { c->inject_timeout = value != 0; return C3D_OK; }   // test hook
     if (!strcmp(key, "narrow_columns")) { c->narrow_columns = value != 0; free_replica_buffers(c); drop_graphs(c); return C3D_OK; }
+    if (!strcmp(key, "cluster_static_placement")) { c->static_place = value != 0; c->inject_misplaced = value == 2; return C3D_OK; }   // 0: per-XCD atomic slot counters; 2: test hook
     if (!strcmp(key, "cluster_inject_incomplete")) { c->inject_incomplete = value != 0; return C3D_OK; }   // test hook
     if (!strcmp(key, "cluster_num_xcc")) { c->num_xcc = (int)value; free_replica_buffers(c); return C3D_OK; }   // test hook: pretend a partitioned device
     if (!strcmp(key, "cluster_geometry")) {  // measurement knob: 100 CW + 10 RPW + helpers (0 = planner); before c3d_init_replicas
@@ -923,10 +931,6 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
         {
             c3d::DevModel m = dev_model(c);
             m.nrep = nrep; m.nrep_g = nrep; m.rep_base = 0;
-            const c3d::AnnealIO io[2] = {c3d::anneal_io(c->buf, 0), c3d::anneal_io(c->buf, 1)};
-            HIP_TRY(hipMalloc(&c->d_io, sizeof(io)));
-            HIP_TRY(hipMemcpyAsync(c->d_io, io, sizeof(io), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
             // symmetric-tile kernels (large N): tile list and the partial-force slabs
             if (!general_tail(m) && c->sym > 0) {
                 int Q, G, od, dg;
@@ -1192,6 +1196,8 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     else if (!strcmp(key, "cluster_launches")) *value = (double)c->cluster_launches;
     else if (!strcmp(key, "resident_fallbacks")) *value = (double)c->resident_fallbacks;
     else if (!strcmp(key, "cluster_incomplete")) *value = (double)c->cluster_incomplete;
+    else if (!strcmp(key, "cluster_static_placement")) *value = c->static_place ? 1.0 : 0.0;
+    else if (!strcmp(key, "cluster_placement_mismatches")) *value = (double)c->placement_mismatches;
     else if (!strcmp(key, "num_xcc")) *value = (double)c->num_xcc;
     else if (!strcmp(key, "rms_force")) {
         // max over the replicas of the RMS force component at the last minimiser evaluation (what c3d_run compares with

@@ -55,10 +55,10 @@ __device__ unsigned long long g_cstamps[64][8];
 
 template <int POT, int RPW, int NB, int WL>
 __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
-    const AnnealIO* __restrict__ io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
+    const AnnealIO io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
     const StepRun* __restrict__ runs, const int run0, const int skip0, const int nsteps, const unsigned tag_base,
     volatile unsigned* __restrict__ timeout, unsigned* __restrict__ claim, const int P, const int CW, const int NH,
-    const unsigned expected, const DevModel m, const DevFire fp) {
+    const unsigned expected, const int static_place, const DevModel m, const DevFire fp) {
     constexpr int NPAD = 256 * NB;
     constexpr int MAXT = NPAD / 8;
     constexpr int KUMAX = NB > 2 ? 3 : 2;         // gather loads per thread: P * 2 RW <= threads * KUMAX
@@ -78,11 +78,24 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const int nthreads = (CW + NH) * 64;           // NH helper waves: H0 + (NH - 1) chain helpers
     const int RW = CW * RPW;                      // rows of one workgroup: a multiple of 8 (whole tiles), <= 64
 
-    // ---- placement: (replica, part) from this XCD's slot counter ---------------------------------
+    // ---- placement: (replica, part) from a slot number inside this workgroup's XCD -------------------------
+    // static_place: the workgroups of a launch are dealt to the XCDs round-robin in launch order — XCD (blockIdx + o) % 8 with
+    // an offset o that is constant for the launch (0 on the null stream, 7 on this library's stream: tools/microbench/
+    // xcc_dispatch.hip) — so blockIdx / 8 numbers the workgroups of every XCD without collision, and without the atomic round
+    // trip of a slot counter (~2 us of every launch).  Not trusted blindly: every workgroup ORs the offset IT sees into one
+    // word, and the workgroup that completes the launch refuses the completion mark unless exactly one offset was seen
+    // (timeout[2] tells the host why; it re-runs the range step by step and switches this context to the counters).
     const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0x7);     // HW_REG_XCC_ID
-    if (tid == 0) *s_slot = (int)atomicAdd(&claim[xcc], 1u);
-    __syncthreads();
-    const int slot = *s_slot;
+    int slot;
+    if (static_place) {
+        const unsigned off = ((unsigned)xcc - blockIdx.x + (static_place == 2 && blockIdx.x == 0 ? 1u : 0u)) & 7u;      // 2: test hook
+        if (tid == 0) atomicOr(&claim[9], 1u << off);
+        slot = (int)(blockIdx.x >> 3);
+    } else {
+        if (tid == 0) *s_slot = (int)atomicAdd(&claim[xcc], 1u);
+        __syncthreads();
+        slot = *s_slot;
+    }
     const int lrep = xcc + 8 * (slot / P), part = slot % P;       // replica index inside this launch's group
     if (lrep >= m.nrep_g) return;                 // this CU has nothing to do
     const int rep = m.rep_base + lrep;
@@ -144,15 +157,15 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     float vcx = 0.0f, vcy = 0.0f, vcz = 0.0f;     // H0: velocity of this lane's row, carried from step to step
     FireState st;
     {
-        const float* xin = io->xin;
-        const float* pin = io->pin;
-        const float* vin = io->vin;
+        const float* xin = io.xin;
+        const float* pin = io.pin;
+        const float* vin = io.vin;
         for (int b = 4 * tid; b < 3 * NPAD; b += 4 * nthreads)
             *reinterpret_cast<float4*>(smem + b) = *reinterpret_cast<const float4*>(xin + roff + b);
         for (int t = tid; t < m.ntiles; t += nthreads)
             reinterpret_cast<float4*>(ps)[t] = reinterpret_cast<const float4*>(pin)[(size_t)rep * m.ntiles + t];
         if (hfin) { C3D_HROW_INDEX; vcx = vin[ix]; vcy = vin[iy]; vcz = vin[iz]; }
-        st = io->sin[rep];
+        st = io.sin[rep];
     }
     // gather bookkeeping: unit u = tid + nthreads k is unit (u & 1) of row (u >> 1) % RW of part (u >> 1) / RW:
     // unit 0 = {x, y}, unit 1 = {z, s}; s = word (row & 7) of the tile's four sums where row & 7 < 4
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             // ---- K2: pair terms of RPW rows, butterfly sums, three words per row for H0 ------------------
             if (p.kind != 4) {
                 float Fx, Fy, Fz;
-                tile_pair_sums_reg<POT, RPW, NB, WL, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
+                tile_pair_sums_reg<POT, RPW, NB, WL, 1>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
                 if (lane < RPW) {
                     const int k = cwave * RPW + lane;
                     fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz;
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 }
                 float vx0 = vcx, vy0 = vcy, vz0 = vcz;
                 if (p.kind == 3) { vx0 = vy0 = vz0 = 0.0f; }
-                else if (p.kind == 4) { C3D_HROW_INDEX; const float* vinit = io->vinit; vx0 = vinit[ix]; vy0 = vinit[iy]; vz0 = vinit[iz]; }
+                else if (p.kind == 4) { C3D_HROW_INDEX; const float* vinit = io.vinit; vx0 = vinit[ix]; vy0 = vinit[iy]; vz0 = vinit[iz]; }
                 finish_row(m, p, fp, sc, st, Fx, Fy, Fz, hx0, hy0, hz0, vx0, vy0, vz0, xn, yn, zn, vcx, vcy, vcz, q);
                 if (!last && !solo) {               // the row's new position leaves at once; the tile sums follow below
                     u32x4 o;
@@ -292,19 +305,23 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             if (last) {                             // hand the state back to the ordinary buffers
                 if (hfin) {
                     C3D_HROW_INDEX;
-                    float* xout = io->xout;
-                    float* vout = io->vout;
+                    float* xout = io.xout;
+                    float* vout = io.vout;
                     xout[ix] = xn; xout[iy] = yn; xout[iz] = zn;
                     vout[ix] = vcx; vout[iy] = vcy; vout[iz] = vcz;
                 }
                 const int tl = (wg_row0 + lane) >> 3;
-                if ((lane & 7) == 0 && lane < RW && tl < m.ntiles) reinterpret_cast<float4*>(io->pout)[(size_t)rep * m.ntiles + tl] = t;
-                if (lane == 0 && part == 0) io->sout[rep] = st;
+                if ((lane & 7) == 0 && lane < RW && tl < m.ntiles) reinterpret_cast<float4*>(io.pout)[(size_t)rep * m.ntiles + tl] = t;
+                if (lane == 0 && part == 0) io.sout[rep] = st;
                 // completion: claim[8] counts the workgroups that reached their last step; the one that completes the launch's
                 // `expected` = replicas x parts says so in the host-mapped word next to *timeout.  A launch in which some
                 // (replica, part) was never claimed (fewer workgroups on an XCD than the plan assumes) or abandoned never
                 // writes it, and the host re-runs the range on the per-step path instead of accepting stale state.
-                if (lane == 0 && atomicAdd(&claim[8], 1u) + 1u == expected) timeout[1] = tag_base | 1u;
+                if (lane == 0 && atomicAdd(&claim[8], 1u) + 1u == expected) {
+                    const unsigned seen = static_place ? atomicOr(&claim[9], 0u) : 1u;       // XCD offsets the workgroups saw
+                    if ((seen & (seen - 1u)) == 0u) timeout[1] = tag_base | 1u;
+                    else timeout[2] = 1u;
+                }
             } else if (solo) {
                 // one workgroup owns the replica: new positions and tile sums go straight back into LDS
                 if (lane < RW && hrow < NPAD) { xs[hrow] = xn; ys[hrow] = yn; zs[hrow] = zn; }
@@ -422,7 +439,7 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
 size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl) { (void)pl; return (size_t)2 * m.nrep_g * (m.npad + m.npad / 4) * 16; }
 
 template <int POT, int RPW, int NB, int WL>
-static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
+static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                              const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                              hipStream_t s) {
     // per (instantiation, device): more dynamic LDS than the 64 KB a launch gets by default.  Contexts of several host
@@ -436,14 +453,14 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
     }
     if (pl.t0 && pl.t1)
         hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, WL>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
-                              reinterpret_cast<u32x4*>(rec), runs, run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, m, fp);
+                              reinterpret_cast<u32x4*>(rec), runs, run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, pl.static_place, m, fp);
     else
         hipLaunchKernelGGL((k_cluster<POT, RPW, NB, WL>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
-                           run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, m, fp);
+                           run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, pl.static_place, m, fp);
     return hipGetLastError();
 }
 template <int POT>
-static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
+static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                                const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                                hipStream_t s) {
 #define C3D_CL(R, B)                                                                                                    \
@@ -464,7 +481,7 @@ static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const Clust
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
+hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                           hipStream_t s) {
     switch (m.noe_pot) {

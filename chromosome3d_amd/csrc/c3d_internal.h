@@ -93,7 +93,7 @@ struct StepRun {    // `count` consecutive steps with the same parameters
     DevStep p;
     int count;
 };
-struct AnnealIO {   // state buffers of one multi-step launch, in device memory (io = anneal_io(buffers, parity) uploaded by the host)
+struct AnnealIO {   // state buffers of one multi-step launch (io = anneal_io(buffers, parity)), passed by value in the kernel arguments
     const float *pin, *xin, *vin, *vinit;
     const FireState* sin;
     float *xout, *vout, *pout;
@@ -111,13 +111,14 @@ AnnealIO anneal_io(const DevBuffers& b, int parity);
 // completes the launch's pl.expected).
 struct ClusterPlan {
     int rpw, cw, helpers, wgs_per_cu, parts, per_xcd, grid, threads, units, device;
+    int static_place = 1;                         // slot = blockIdx / 8, checked against the XCC id (0: per-XCD atomic counters)
     unsigned expected = 0;                        // workgroups that must report completion: replicas x parts (the host may raise it: test hook)
     size_t lds;
     hipEvent_t t0 = nullptr, t1 = nullptr;        // when set: the launch stamps them with the kernel's own start and end
 };
 bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, ClusterPlan* plan);
 size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl);
-hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO* io, const float* tgt, void* rec,
+hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout,
                           unsigned* claim, hipStream_t s);
 // symmetric-tile step for large N (c3d_sym.hip): every pair once.  tiles = sym_tile_list() uploaded, scratch =

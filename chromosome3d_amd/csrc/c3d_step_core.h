@@ -371,7 +371,7 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
 // WITHOUT the row factor (pair_sum_scaled): lane l holds the sum for row row0 + (l & 3) (RPW >= 3), row0 + (l & 1) (RPW = 2),
 // row0 (RPW = 1); factor and chain terms are added by the finishing wave.
 // NARROW = keep only four pair terms in flight (register budget).
-template <int POT, int RPW, int NB, int WL, bool NARROW>
+template <int POT, int RPW, int NB, int WL, int NARROW>
 __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevStep& p, const float4 (&tv)[RPW][NB],
                                                    const float4* mw_lds, const float* xs, const float* ys, const float* zs,
                                                    int row0, int lane, float& Fx, float& Fy, float& Fz) {
@@ -404,7 +404,12 @@ __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevS
             const float4 mw = mw_lds[(r * NB + jb) * 64 + lane];
             if (width == 4) pair_quad<POT, false>(m, p, k, tv[r][jb], mw, xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
             else pair_quad_w<POT, false>(m, p, k, width, tv[r][jb], mw, xi[r], yi[r], zi[r], xj, yj, zj, fx[r], fy[r], fz[r]);
-            if constexpr (NARROW) asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]));   // four pair terms in flight, not 4 RPW NB
+            if constexpr (NARROW == 1) asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]));   // four pair terms in flight, not 4 RPW NB
+            if constexpr (NARROW == 2) { if (r & 1) asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]), "+v"(fx[r - 1]), "+v"(fy[r - 1]), "+v"(fz[r - 1])); }   // eight
+        }
+        if constexpr (NARROW == 3) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(fx[r]), "+v"(fy[r]), "+v"(fz[r]));           // one block of all rows
         }
     }
     Fx = reduce_rows<RPW>(fx, lane);

@@ -111,6 +111,9 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *   cluster         0: never use the cluster kernel (test knob)
  *   cluster_geometry  100 x compute waves + 10 x rows per wave + helper waves (e.g. 1244): force that geometry of the cluster
  *                   kernel instead of the planner's choice (measurement knob; 0 = planner); before c3d_init_replicas
+ *   cluster_static_placement  1 (default): a cluster launch numbers the workgroups of an XCD as blockIdx / 8 and every workgroup
+ *                   checks its XCC id against blockIdx % 8; a mismatch abandons the launch and switches the context to 0 =
+ *                   per-XCD atomic slot counters (2: test hook, the next launch's workgroup 0 reports a mismatch)
  *   cluster_num_xcc, cluster_inject_incomplete, resident_inject_timeout   test hooks of the cluster kernel's safety net
  *                   (a device that does not expose 8 XCDs gets no cluster plan; a launch that ends without its completion
  *                   mark or with a time-out is re-run on the per-step path)
@@ -154,7 +157,8 @@ int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* lau
  * only instrument is the wall clock around `./job.sh`, chromosome3D.pl:287).  Keys: "graph_captures" (hipGraphs
  * captured + instantiated), "graph_launches", "graphs_cached", "step_launches" (k_step dispatches), "resident_launches",
  * "cluster_launches", "resident_fallbacks" (multi-step launches abandoned for the per-step path), "cluster_incomplete"
- * (those of them that ended without every (replica, part) workgroup reporting), "num_xcc", "last_path"
+ * (those of them that ended without every (replica, part) workgroup reporting), "cluster_static_placement",
+ * "cluster_placement_mismatches", "num_xcc", "last_path"
  * (0 per-step, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "cluster_compute_waves", "replica_groups",
  * "k1_recomputed" (elements of the last c3d_set_if_matrix that sat within 1e-10 of a "%.1f" rounding tie and were redone
  * on the host in the reference's operation order), "k1_patched" (how many of those changed, since c3d_create),

@@ -638,3 +638,22 @@ def test_no_cluster_plan_on_a_device_without_eight_xcds(solver):
         assert np.array_equal(xa, xb) and np.array_equal(ea, eb)
     finally:
         solver.set_option("cluster_num_xcc", 8)
+
+
+def test_cluster_placement_mismatch_switches_to_the_slot_counters(solver):
+    """A cluster launch numbers the workgroups of an XCD as blockIdx / 8 (workgroups are dealt to the XCDs round-robin) and
+    every workgroup checks that against its XCC id.  A mismatch (injected: workgroup 0 reports one) abandons the launch,
+    the range runs step by step, and the context claims slots from per-XCD atomic counters from then on — same bits."""
+    xa, va, ea, ta = _anneal(solver, "chr1_500kb", 3, 0)
+    assert solver.stat("cluster_static_placement") == 1
+    before = solver.stat("cluster_placement_mismatches")
+    solver.set_option("cluster_static_placement", 2)
+    try:
+        xb, vb, eb, tb = _anneal(solver, "chr1_500kb", 3, 1)
+        assert solver.stat("cluster_placement_mismatches") == before + 1 and solver.stat("cluster_static_placement") == 0
+        assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(ea, eb)
+        xc, vc, ec, tc = _anneal(solver, "chr1_500kb", 3, 1)          # now on the counters, as one launch per range again
+        assert tc[2] < 40 and solver.stat("last_path") == 2
+        assert np.array_equal(xa, xc) and np.array_equal(ea, ec)
+    finally:
+        solver.set_option("cluster_static_placement", 1)

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(1024) void k_loop(const float* __restrict__ in, flo
         if constexpr (MODE >= 1) __syncthreads();
         if (is_compute) {
             float Fx, Fy, Fz;
-            tile_pair_sums_reg<3, RPW, NB, 4, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
+            tile_pair_sums_reg<3, RPW, NB, 4, 1>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
             if (lane < RPW) { const int k = cwave * RPW + lane; fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz; }
             acc += Fx;
         }

@@ -82,9 +82,10 @@ __global__ __launch_bounds__(1024) void k_loop(const float* __restrict__ in, flo
         __syncthreads();
         if (is_compute) {
             float Fx, Fy, Fz;
-            if constexpr (FORM == 0) tile_pair_sums_reg<3, RPW, NB, 4, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);   // the product's form
-            else if constexpr (FORM == 10) tile_pair_sums_reg<3, RPW, NB, 3, true>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);   // last block 3 columns per lane (N = 455)
-            else if constexpr (FORM == 11) tile_pair_sums_reg<3, RPW, NB, 3, false>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);  // the same, scheduler unconstrained
+            if constexpr (FORM == 0) tile_pair_sums_reg<3, RPW, NB, 4, 1>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);   // the product's form
+            else if constexpr (FORM == 10) tile_pair_sums_reg<3, RPW, NB, 3, 1>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);   // last block 3 columns per lane (N = 455)
+            else if constexpr (FORM == 11) tile_pair_sums_reg<3, RPW, NB, 3, 2>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);  // eight pair terms in flight
+            else if constexpr (FORM == 12) tile_pair_sums_reg<3, RPW, NB, 3, 3>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);  // a whole block of all rows in flight
             else tile_s<RPW, NB>(k2.nm, k2.kq, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
             if (lane < RPW) { const int k = cwave * RPW + lane; fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz; }
             acc += Fx;
@@ -121,7 +122,8 @@ int main() {
     struct { int form, rpw, cw, nh; const char* what; } cases[] = {
         {0, 4, 12, 4, "product form (c3d_step_core.h, 15 instr)   12 x 4 rows + 4 idle"},
         {10, 4, 12, 4, "product form, 7 column slots (N = 455)     12 x 4 rows + 4 idle"},
-        {11, 4, 12, 4, "product form, 7 slots, not NARROW          12 x 4 rows + 4 idle"},
+        {11, 4, 12, 4, "product form, 7 slots, 8 terms in flight   12 x 4 rows + 4 idle"},
+        {12, 4, 12, 4, "product form, 7 slots, 16 terms in flight  12 x 4 rows + 4 idle"},
         {1, 4, 12, 4, "F1 scaled form (15 instr)                  12 x 4 rows + 4 idle"},
         {0, 3, 16, 0, "product form                               16 x 3 rows"},
         {1, 3, 16, 0, "F1 scaled form                             16 x 3 rows"},
@@ -135,6 +137,7 @@ int main() {
         if (c.form == 0 && c.rpw == 4) ms = run<0, 4>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
         else if (c.form == 10 && c.rpw == 4) ms = run<10, 4>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
         else if (c.form == 11 && c.rpw == 4) ms = run<11, 4>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
+        else if (c.form == 12 && c.rpw == 4) ms = run<12, 4>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
         else if (c.form == 1 && c.rpw == 4) ms = run<1, 4>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
         else if (c.form == 0 && c.rpw == 3) ms = run<0, 3>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
         else if (c.form == 1 && c.rpw == 3) ms = run<1, 3>(grid, threads, lds, in, out, iters, c.cw, c.nh, m, p, k2, e0, e1);
