@@ -19,11 +19,11 @@ use File::Basename;
 use File::Copy;
 use Getopt::Long;
 
-my ($help, $dir_out, $file_if, $shape_only);
+my ($help, $dir_out, $file_if, $shape_only, $file_seq);
 my ($K, $ALPHA, $MODELS) = (11, 0.5, 20);        # chromosome3D.pl:18-21
 my ($SEED, $DEVICE, $DISTRELAX) = (82364, 0, 0.5);  # :980, :74
 GetOptions("h" => \$help, "o=s" => \$dir_out, "k=i" => \$K, "a=s" => \$ALPHA, "m=i" => \$MODELS,
-           "i|if=s" => \$file_if, "seed=i" => \$SEED, "device=i" => \$DEVICE, "shape=s" => \$shape_only)
+           "i|if=s" => \$file_if, "seed=i" => \$SEED, "device=i" => \$DEVICE, "shape=s" => \$shape_only, "seq=s" => \$file_seq)
 	or die "ERROR! Error in command line arguments!\n";
 usage() if $help;
 # residue names a model row may carry (the 20 standard amino acids; rows with any other name are dropped, reference :847)
@@ -64,10 +64,21 @@ chdir $dir_out or die $!;
 
 # <ID>.fasta (:92-98): one residue per bead.  Every bead is written as MET, as in the bundled output_models, so the
 # sequence file that goes with the models is M x L (the reference cuts L letters out of a fixed pseudo-protein)
+# -seq <fasta>: name the residues after the first L letters of that sequence instead, as a reference run does with its
+# fixed 663-letter pseudo-protein (:93-94; chromosome3d_amd/data/refsequence.fasta holds it); beads beyond its end stay MET
+my $sequence;
 {
 	my $L = first_line_fields("$ID.txt");
+	$sequence = "M" x $L;
+	if (defined $file_seq) {
+		open my $sq, "<", $file_seq or die "ERROR! cannot read $file_seq: $!\n";
+		my $letters = join "", map { s/\s+//gr } grep { !/^>/ } <$sq>;
+		close $sq;
+		$sequence = substr($letters, 0, $L);
+		$sequence .= "M" x ($L - length $sequence);
+	}
 	open my $fa, ">", "$ID.fasta" or die $!;
-	print $fa ">$ID\n", "M" x $L, "\n";
+	print $fa ">$ID\n", $sequence, "\n";
 	close $fa;
 }
 
@@ -77,6 +88,7 @@ if ($have_xs) {
 	# in-process FFI: Perl -> XS -> C ABI -> HIP kernels
 	print "(B) Build models using libc3d (MI355X) through the C3D XS binding..\n";
 	system("touch iam.running");
+	C3D::set_sequence(defined $file_seq ? $sequence : "");
 	my $r = eval { C3D::solve("$ID.txt", ".", $ID, $MODELS, $K, $ALPHA + 0, $SEED, $DEVICE, 0) };
 	if (not defined $r) {
 		rename "iam.running", "iam.failed";
@@ -92,7 +104,7 @@ else {
 # the process boundary of the reference, same sentinel protocol (:258-288)
 open my $job, ">", "job.sh" or die $!;
 print $job "#!/bin/bash\necho \"starting c3d_solve..\"\ntouch iam.running\n";
-print $job "\"$solver\" --if \"$ID.txt\" --out . --id \"$ID\" -k $K -a $ALPHA -m $MODELS --seed $SEED --device $DEVICE\n";
+print $job "\"$solver\" --if \"$ID.txt\" --out . --id \"$ID\" -k $K -a $ALPHA -m $MODELS --seed $SEED --device $DEVICE".(defined $file_seq ? " --seq $sequence" : "")."\n";
 print $job "if [ -f \"${ID}_${MODELS}.pdb\" ]; then\n   rm -f iam.running\n   echo \"trial structures written.\"\n   exit\nfi\n";
 print $job "echo \"ERROR! Final structures not found!\"\nmv iam.running iam.failed 2>/dev/null || touch iam.failed\n";
 close $job;
@@ -211,6 +223,7 @@ PARAM        DESCRIPTION
 -a        :  Alpha for the IF -> distance conversion (default 0.5)
 -m        :  Number of models to generate (default 20)
 --seed    :  RNG seed (default 82364)   --device : GPU index (default 0)
+--seq     :  FASTA file naming the residues (the reference's pseudo-protein: chromosome3d_amd/data/refsequence.fasta; default: all MET)
 Example: $0 -i ./input/chr22_1mb_matrix.txt -o ./output/chr22_1mb
 EOU
 	exit(defined $msg ? 1 : 0);

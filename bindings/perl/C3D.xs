@@ -46,6 +46,14 @@ device_count()
     OUTPUT:
         RETVAL
 
+int
+set_sequence(seq1)
+        const char* seq1
+    CODE:
+        RETVAL = c3d_set_residue_sequence(seq1);
+    OUTPUT:
+        RETVAL
+
 SV*
 solve(matrix_path, out_dir, id, models, K, alpha, seed, device, embed)
         const char* matrix_path

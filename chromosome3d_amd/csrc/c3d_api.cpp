@@ -218,7 +218,9 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
         const int cols_last = c->n - (c->npad - 256);
         int wl = cols_last / 64, nleft = cols_last - 64 * wl;
         if (wl == 0 || nleft > 8) { wl = std::min(4, wl + 1); nleft = 0; }
-        if (!c->narrow_columns) { wl = 4; nleft = 0; }
+        // beyond the cluster kernel's reach (npad > 1024: the per-step kernel streams the targets) one column slot in 40 is not worth
+        // the narrow block's scalar loads and the left-over pass: 28.0 against 27.0 us per step at N = 2500
+        if (!c->narrow_columns || c->npad > 1024) { wl = 4; nleft = 0; }
         m.wl = wl; m.nleft = nleft; m.jl0 = c->npad - 256 + 64 * wl;
     }
     m.mtail_c = h.masym;
@@ -1231,7 +1233,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %d>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, m.wl);
     else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);
     else if (c->precision == 64) snprintf(buf, sizeof(buf), "c3d::k64_force");
-    else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d>", m.noe_pot, gen, m.rpw);
+    else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d, %s>", m.noe_pot, gen, m.rpw, (m.wl == 4 && m.nleft == 0) ? "false" : "true");
     return buf;
 }
 

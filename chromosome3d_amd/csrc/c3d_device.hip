@@ -59,7 +59,7 @@ inline dim3 grid_blocks(const DevModel& m) { return dim3(8, m.nrep_g, (m.ntiles 
 //   4. lanes 0..RPW-1 finish one row each; tile partial sums through LDS
 // ---------------------------------------------------------------------------------------------
 
-template <int POT, bool GEN, int RPW>
+template <int POT, bool GEN, int RPW, bool NC>
 __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     const float* __restrict__ pin, const float* __restrict__ xin, const float* __restrict__ tgt,
     const float* __restrict__ vin, const float* __restrict__ vinit, const FireState* __restrict__ sin,
@@ -69,15 +69,17 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     constexpr int BLOCK = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     C3D_STAMP(6);      // before any kernel argument beyond the preloaded ones is needed
-    {   // The 244-byte kernarg block spans four 64-byte lines and the scalar cache is cold at every launch: the
+    {   // The 280-byte kernarg block spans five 64-byte lines and the scalar cache is cold at every launch: the
         // compiler fetches the arguments where they are first used, one ~550-cycle miss after the other.  Touch
-        // the three lines beyond the preloaded pointers at once; the later loads then hit.
-        static_assert(10 * sizeof(void*) + sizeof(DevModel) + sizeof(DevStep) + sizeof(DevFire) >= 0xc0 + 4,
+        // the four lines beyond the preloaded pointers at once; the later loads then hit.
+        static_assert(10 * sizeof(void*) + sizeof(DevModel) + sizeof(DevStep) + sizeof(DevFire) >= 0x100 + 4,
                       "the touched offsets must lie inside the explicit kernel arguments");
+        static_assert(10 * sizeof(void*) + sizeof(DevModel) + sizeof(DevStep) + sizeof(DevFire) <= 0x140,
+                      "a sixth 64-byte line of kernel arguments needs a sixth touch");
         const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-        unsigned t0, t1, t2;
-        asm volatile("s_load_dword %0, %3, 0x40\n\ts_load_dword %1, %3, 0x80\n\ts_load_dword %2, %3, 0xc0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(t0), "=&s"(t1), "=&s"(t2) : "s"(ka) : "memory");
+        unsigned t0, t1, t2, t3;
+        asm volatile("s_load_dword %0, %4, 0x40\n\ts_load_dword %1, %4, 0x80\n\ts_load_dword %2, %4, 0xc0\n\ts_load_dword %3, %4, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(ka) : "memory");
     }
     int tile, rep;
     if (!block_to_tile(m, tile, rep)) return;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     float4 q0 = make_float4(0, 0, 0, 0);
     if (needs_partials && lane < m.ntiles) q0 = pp[lane];
     float4 tv[RPW];
-    if (p.kind != 4) tile_prefetch<RPW>(m, tgt, row0, lane, 0, tv);
+    if (p.kind != 4) tile_prefetch<RPW, NC>(m, tgt, row0, lane, 0, tv);
     float vx0 = 0.0f, vy0 = 0.0f, vz0 = 0.0f;
     if (finisher && p.kind != 3) {
         const float* vsrc = p.kind == 4 ? vinit : vin;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
 
     // ---- 3. K2: pair forces for this wave's rows ---------------------------------------------
     float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
-    if (p.kind != 4) tile_forces<POT, GEN, RPW>(m, p, tgt, xs, ys, zs, row0, lane, tv, Fx, Fy, Fz);
+    if (p.kind != 4) tile_forces<POT, GEN, RPW, NC>(m, p, tgt, xs, ys, zs, row0, lane, tv, Fx, Fy, Fz);
 
     C3D_STAMP(4);
     // ---- 4. epilogue: lanes 0..RPW-1 finish one row each --------------------------------------
@@ -162,8 +164,12 @@ template <int POT, bool GEN, int RPW>
 static hipError_t launch_step_r(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
                                 hipStream_t s) {
     const int q = par ^ 1;
-    hipLaunchKernelGGL((k_step<POT, GEN, RPW>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
-                       b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
+    if (m.wl == 4 && m.nleft == 0)      // no narrow last block, no left-over columns: the variant without that code
+        hipLaunchKernelGGL((k_step<POT, GEN, RPW, false>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
+                           b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
+    else
+        hipLaunchKernelGGL((k_step<POT, GEN, RPW, true>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
+                           b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
     return hipGetLastError();
 }
 template <int POT, bool GEN>

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -245,6 +246,29 @@ extern "C" int c3d_read_tbl(const char* path, int32_t** ri, int32_t** rj, int32_
 // Residue names carry no physics in the bead model; any of the 20 standard names keeps the
 // reference's reindex_chain / seq_chain (chromosome3D.pl:847, :225) happy.  The bundled
 // output_models use MET for every bead, so do we.
+// residue names: one-letter codes of the pseudo-protein a caller may install (chromosome3D.pl:93-98), else MET
+namespace {
+std::mutex g_seq_mu;
+std::string g_seq1;
+const char* three_letter(char c) {     // %AA1TO3 (chromosome3D.pl:77-78)
+    switch (c) {
+        case 'A': return "ALA"; case 'N': return "ASN"; case 'C': return "CYS"; case 'Q': return "GLN"; case 'H': return "HIS";
+        case 'L': return "LEU"; case 'M': return "MET"; case 'P': return "PRO"; case 'T': return "THR"; case 'Y': return "TYR";
+        case 'R': return "ARG"; case 'D': return "ASP"; case 'E': return "GLU"; case 'G': return "GLY"; case 'I': return "ILE";
+        case 'K': return "LYS"; case 'F': return "PHE"; case 'S': return "SER"; case 'W': return "TRP"; case 'V': return "VAL";
+        default: return "MET";
+    }
+}
+}  // namespace
+extern "C" int c3d_set_residue_sequence(const char* seq1) {
+    std::lock_guard<std::mutex> lk(g_seq_mu);
+    g_seq1.clear();
+    if (seq1)
+        for (const char* p = seq1; *p; ++p)
+            if (!is_ws(*p)) g_seq1.push_back((char)toupper((unsigned char)*p));
+    return C3D_OK;
+}
+
 extern "C" int c3d_write_pdb(const char* path, const float* xyz, int n, double e_noe, double e_bond, double e_rep,
                              const char* title) {
     if (!path || !xyz || n < 1) return fail(C3D_ERR_INVALID, "c3d_write_pdb: bad arguments");
@@ -257,8 +281,10 @@ extern "C" int c3d_write_pdb(const char* path, const float* xyz, int n, double e
     fprintf(f, "REMARK vdw = %.4f\n", e_rep);
     fprintf(f, "REMARK noe = %.4f\n", e_noe);
     fprintf(f, "REMARK ===============================================================\n");
+    std::string seq;
+    { std::lock_guard<std::mutex> lk(g_seq_mu); seq = g_seq1; }
     for (int i = 0; i < n; ++i) {
-        const char* rn = "MET";
+        const char* rn = (size_t)i < seq.size() ? three_letter(seq[i]) : "MET";
         // cols: 1-6 ATOM, 7-11 serial, 13-16 name, 18-20 resName, 22 chain(blank), 23-26 resSeq, 31-54 xyz
         fprintf(f, "ATOM  %5d  CA  %3s  %4d    %8.3f%8.3f%8.3f  1.00  0.00\n", (i + 1) % 100000, rn, (i + 1) % 10000,
                 (double)xyz[3 * i], (double)xyz[3 * i + 1], (double)xyz[3 * i + 2]);

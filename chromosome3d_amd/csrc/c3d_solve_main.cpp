@@ -23,7 +23,8 @@ static void usage() {
     fprintf(stderr,
             "usage: c3d_solve (--if <IF matrix> | --tbl <contact.tbl> --n <beads>) --out <dir> [--id <ID>]\n"
             "                 [-k <K=11>] [-a <alpha=0.5>] [-m <models=20>] [--seed <82364>] [--first-replica <0>]\n"
-            "                 [--device <0>] [--min-steps <3000>] [--gtol <1e-2>] [--embed] [--no-graph] [--quiet]\n");
+            "                 [--device <0>] [--min-steps <3000>] [--gtol <1e-2>] [--embed] [--no-graph] [--quiet]\n"
+            "                 [--seq <one-letter residue codes | @fasta file>   residue names of the models (default: all MET)]\n");
 }
 
 #define CHECK(call)                                                              \
@@ -48,7 +49,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 int main(int argc, char** argv) {
     const double t_start = now_s();
-    std::string if_path, tbl_path, out_dir, id;
+    std::string if_path, tbl_path, out_dir, id, seq_arg;
     double K = 11, alpha = 0.5, gtol = 1e-2;
     int models = 20, device = 0, n_beads = 0, min_steps = 3000, use_graph = 1, quiet = 0, embed = 0;
     unsigned long long seed = 82364ULL;
@@ -75,6 +76,7 @@ int main(int argc, char** argv) {
         else if (s == "--embed") embed = 1;   // distance-geometry start (deck :1471-1525) instead of the random coil
         else if (s == "--no-graph") use_graph = 0;
         else if (s == "--quiet") quiet = 1;
+        else if (s == "--seq") seq_arg = next("--seq");
         else if (s == "-h" || s == "--help") { usage(); return 0; }
         else { fprintf(stderr, "c3d_solve: unknown option %s\n", s.c_str()); usage(); return 2; }
     }
@@ -83,6 +85,18 @@ int main(int argc, char** argv) {
         std::string base = if_path.empty() ? std::string("model") : if_path.substr(if_path.find_last_of('/') + 1);
         if (base.size() > 4 && base.substr(base.size() - 4) == ".txt") base.resize(base.size() - 4);
         id = base;
+    }
+    if (!seq_arg.empty()) {           // residue names: letters, or @file in FASTA form (header lines skipped)
+        std::string letters = seq_arg;
+        if (seq_arg[0] == '@') {
+            FILE* f = fopen(seq_arg.c_str() + 1, "r");
+            if (!f) { fprintf(stderr, "c3d_solve: cannot read %s\n", seq_arg.c_str() + 1); return 2; }
+            letters.clear();
+            char line[4096];
+            while (fgets(line, sizeof line, f)) if (line[0] != '>') letters += line;
+            fclose(f);
+        }
+        c3d_set_residue_sequence(letters.c_str());
     }
     mkdir(out_dir.c_str(), 0755);   // like the reference (:45): create the output directory if missing
     { FILE* f = fopen((out_dir + "/iam.running").c_str(), "w"); if (!f) { fprintf(stderr, "c3d_solve: cannot write into %s\n", out_dir.c_str()); return 1; } fclose(f); }

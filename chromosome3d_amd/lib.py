@@ -79,6 +79,7 @@ SIGNATURES = {
     "c3d_write_front_half": (_i, [_i32p, _i, _i, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_i)]),
     "c3d_read_tbl": (_i, [C.c_char_p, C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_i)]),
     "c3d_write_pdb": (_i, [C.c_char_p, _fp, _i, _d, _d, _d, C.c_char_p]),
+    "c3d_set_residue_sequence": (_i, [C.c_char_p]),
     "c3d_shape_pdb": (_i, [C.c_char_p, C.c_char_p, C.c_char_p]),
     "c3d_read_pdb_ca": (_i, [C.c_char_p, C.POINTER(_fp), C.POINTER(_i)]),
     "c3d_assess": (_i, [_fp, _i, _i, _i32p, _i32p, _i32p, _d, C.POINTER(_i), _dp]),

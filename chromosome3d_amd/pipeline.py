@@ -80,6 +80,21 @@ def restraints_from_dist10(dist10, min_sep=SEPARATION):
     return (i[m] + 1).astype(np.int32), (j[m] + 1).astype(np.int32), dist10[i, j][m].astype(np.int32)
 
 
+REFSEQUENCE_FASTA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "refsequence.fasta")
+
+
+def read_fasta(path):
+    """letters of a FASTA / plain sequence file (header lines skipped) — seq_fasta, chromosome3D.pl:731-744"""
+    return "".join(l.strip() for l in open(path) if not l.startswith(">"))
+
+
+def set_residue_sequence(seq1):
+    """Residue names of the models written from now on: None -> all MET (the bundled output_models), a string of one-letter
+    codes -> residue i named after letter i as a reference run does (chromosome3D.pl:93-98); read_fasta(REFSEQUENCE_FASTA) is
+    the reference's pseudo-protein."""
+    _l.check(_l.load().c3d_set_residue_sequence(seq1.encode() if seq1 else None))
+
+
 def write_pdb(path, xyz, e_noe=0.0, e_bond=0.0, e_rep=0.0, title=None):
     x = _l.as_f32(xyz)
     _l.check(_l.load().c3d_write_pdb(os.fsencode(path), _l.fptr(x), x.shape[0], e_noe, e_bond, e_rep,

@@ -198,6 +198,12 @@ int c3d_read_tbl(const char* path, int32_t** ri, int32_t** rj, int32_t** rt10, i
  * bundled output_models (MET). */
 int c3d_write_pdb(const char* path, const float* xyz, int n, double e_noe, double e_bond, double e_rep,
                   const char* title);
+/* Residue names of the models c3d_write_pdb writes.  The reference names residue i after letter i of a fixed 663-letter
+ * pseudo-protein (`$REFSEQUENCE`, chromosome3D.pl:93-98; 3-letter codes through %AA1TO3, :78) — the chemistry CNS needs and a
+ * bead model does not; its bundled output_models were re-exported with every residue MET, which is the default here.  seq1 =
+ * one-letter amino-acid codes, one per bead (chromosome3d_amd/data/refsequence.fasta holds the reference's); beads beyond its
+ * end, and letters outside the 20 standard ones, are MET.  NULL or "" restores all-MET.  Process-wide; call before writing. */
+int c3d_set_residue_sequence(const char* seq1);
 int c3d_read_pdb_ca(const char* path, float** xyz, int* n);
 /* A16, what assess_dgsa does to every solver-output PDB before it ranks them (chromosome3D.pl:813-820): filter_nonCA
  * :864-880 (REMARK rows go to `log_path`, appended after a line with the input path; ATOM rows containing "CA" stay),

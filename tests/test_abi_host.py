@@ -192,3 +192,29 @@ def test_threaded_parser_is_exact_and_reports_bad_tokens(built, tmp_path):
     (tmp_path / "short.txt").write_text(text[: text.rstrip().rfind(" ")], newline="")
     with pytest.raises(C3DError):
         pipeline.parse_if_file(str(tmp_path / "short.txt"))
+
+
+def test_residue_names_follow_an_installed_sequence(built, tmp_path):
+    """A reference run names residue i after letter i of its fixed pseudo-protein (chromosome3D.pl:93-98; first residues ARG SER
+    GLU ASP TRP GLN CYS); its bundled models carry MET everywhere, which stays the default.  With the
+    sequence installed the writer names the beads accordingly, the shaping of :813-820 keeps the names, and beads beyond the
+    sequence's end are MET."""
+    import numpy as np
+    from chromosome3d_amd import pipeline
+    seq = pipeline.read_fasta(pipeline.REFSEQUENCE_FASTA)
+    assert len(seq) == 663 and seq.startswith("RSEDWQC")
+    xyz = np.cumsum(np.full((670, 3), 1.5, dtype=np.float32), axis=0)
+    p = str(tmp_path / "m.pdb")
+    try:
+        pipeline.set_residue_sequence(seq)
+        pipeline.write_pdb(p, xyz, 1.0, 2.0, 3.0, title="m.pdb")
+        names = [l[17:20] for l in open(p) if l.startswith("ATOM")]
+        assert names[:7] == ["ARG", "SER", "GLU", "ASP", "TRP", "GLN", "CYS"] and len(names) == 670
+        assert names[662] != "" and names[663:] == ["MET"] * 7
+        pipeline.shape_pdb(p)
+        shaped = [l[17:20] for l in open(p) if l.startswith("ATOM")]
+        assert shaped == names
+    finally:
+        pipeline.set_residue_sequence(None)
+    pipeline.write_pdb(p, xyz[:5])
+    assert [l[17:20] for l in open(p) if l.startswith("ATOM")] == ["MET"] * 5
