@@ -71,7 +71,8 @@ def cpu_baseline(IF, d10, model, fire, stages, budget_s=8.0):
     t0 = time.perf_counter()
     _, _, ev = O.run_schedule(om, d10, O.make_stages(sample), of, 82364, 0, x0=x)
     dt = time.perf_counter() - t0
-    one = (ev / dt, f"1 replica of {WORKLOAD}, {ev} SA steps of the same schedule (hot/cool MD), fp64 oracle/c3d_oracle.c, "
+    kinds = "+".join(sorted({{0: "hot MD", 1: "cool MD", 2: "FIRE"}[r[0]] for r in sample}))
+    one = (ev / dt, f"1 replica of {WORKLOAD}, {ev} SA steps of the same schedule after its first stage ({kinds}), fp64 oracle/c3d_oracle.c, "
                     f"1 core, {dt:.1f} s")
     # the same sample on every host core at once, one replica per thread (the reference's way to use a CPU box is one
     # process per chromosome, test.sh:4-12); ctypes releases the GIL inside the C call
@@ -444,8 +445,9 @@ def main():
             # is explained by the vector-ALU rate: algorithmic flops (30 R + 40 N per replica-step) against the fp32 vector peak
             "valu": {"flops_per_replica_step": 30 * R + 40 * n,
                      "achieved_tflops": round(M * (30 * R + 40 * n) / (kernel_us_region / args.steps * 1e-6) / 1e12, 2),
-                     "peak_tflops": 157.3, "pairs_evaluated_per_replica_step": n * (-(-n // 256) * 256),
-                     "note": "every pair is evaluated from both of its rows (16 VALU instructions each); peak = fp32 vector spec"},
+                     "peak_tflops": 157.3, "pairs_evaluated_per_replica_step": n * n,
+                     "note": "every pair is evaluated from both of its rows (15 VALU instructions each; lanes without a column in the last, "
+                             "narrower block idle); peak = fp32 vector spec"},
             "collective": {"backend": (dist.get_backend() if dist is not None else None), "device": coll_dev, "world": world},
             "gather_ms": round(gather_ms, 3),
             "models_ranked": len(order),
