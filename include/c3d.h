@@ -111,6 +111,10 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *   cluster         0: never use the cluster kernel (test knob)
  *   cluster_geometry  100 x compute waves + 10 x rows per wave + helper waves (e.g. 1244): force that geometry of the cluster
  *                   kernel instead of the planner's choice (measurement knob; 0 = planner); before c3d_init_replicas
+ *   narrow_columns  1 (default) / 0: column layout of the pair loop — the lanes of the last 256-column block own 1..4 columns each and
+ *                   up to 8 columns behind it are summed separately (N = 455: 7 column slots per row instead of 8); 0 = four
+ *                   columns per lane everywhere (round 2's layout).  The two layouts sum in different orders: results agree to
+ *                   rounding, not bit for bit; every launch form follows the layout in force.  Before c3d_init_replicas.
  *   cluster_static_placement  1 (default): a cluster launch numbers the workgroups of an XCD as blockIdx / 8 and every workgroup
  *                   checks its XCC id against blockIdx % 8; a mismatch abandons the launch and switches the context to 0 =
  *                   per-XCD atomic slot counters (2: test hook, the next launch's workgroup 0 reports a mismatch)
