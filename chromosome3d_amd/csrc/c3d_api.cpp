@@ -1330,7 +1330,11 @@ extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
 }
 
 #ifdef C3D_STAMPS
-namespace c3d { hipError_t read_stamps(unsigned long long* out); hipError_t read_cluster_stamps(unsigned long long* out); }
+namespace c3d { hipError_t read_stamps(unsigned long long* out); hipError_t read_cluster_stamps(unsigned long long* out); hipError_t read_cluster_pstamps(unsigned long long* out); }
+extern "C" int c3d_debug_cluster_pstamps(unsigned long long* out) {
+    hipError_t e = c3d::read_cluster_pstamps(out);
+    return e == hipSuccess ? C3D_OK : C3D_ERR_HIP;
+}
 extern "C" int c3d_debug_cluster_stamps(unsigned long long* out) {
     hipError_t e = c3d::read_cluster_stamps(out);
     return e == hipSuccess ? C3D_OK : C3D_ERR_HIP;

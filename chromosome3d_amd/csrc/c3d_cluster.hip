@@ -46,6 +46,9 @@ constexpr int kClMaxThreads = 1024;
 // raw s_memrealtime stamps (100 MHz) of the last 64 steps of a launch: [step & 63][point], written by one lane of the
 // stamping wave (H0 of replica 0 part 0 for points 0..5, compute wave 0 of the same workgroup for points 6..7)
 __device__ unsigned long long g_cstamps[64][8];
+// launch phases of the stamping workgroup: [0] kernel entry, [1] prologue done (targets, coordinates, constants in place), [2] first
+// step started (past the first B1), [3] last step finished (outputs stored, completion counted)
+__device__ unsigned long long g_pstamps[8];
 #define CSTAMP(k) do { if (stamper) g_cstamps[s & 63][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define CSTAMP_C(k) do { if (cstamper) g_cstamps[s & 63][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -74,6 +77,9 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     float* dump = lcon + 3 * 4 * 2 * 64;          // [4] nobody reads
     int* s_slot = reinterpret_cast<int*>(dump + 4);
     // dump + 8 ..: [CW][RPW * NB][64] float4, the compute waves' pair_a constants
+#ifdef C3D_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = (CW + NH) * 64;           // NH helper waves: H0 + (NH - 1) chain helpers
     const int RW = CW * RPW;                      // rows of one workgroup: a multiple of 8 (whole tiles), <= 64
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 #ifdef C3D_STAMPS
     const bool stamper = lrep == 0 && part == 0 && is_h0 && lane == 0;
     const bool cstamper = lrep == 0 && part == 0 && cwave == 0 && lane == 0;
+    if (stamper) { g_pstamps[0] = t_entry; g_pstamps[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     // One step loop PER ROLE (compute wave, H0, chain helper): the waves of a workgroup keep their role for the whole launch, and
     // written as one loop with role branches inside, every role's registers are live in every other role's code (the compiler
@@ -205,6 +212,9 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
       for (int it = run == run0 ? skip0 : 0; it < count; ++it, ++s) {
         __syncthreads();                            // B1: xs/ys/zs/ps of this step are in LDS
         CSTAMP(0);                                  // step start (H0 past B1)
+#ifdef C3D_STAMPS
+        if (stamper && s == 0) g_pstamps[2] = __builtin_amdgcn_s_memrealtime();
+#endif
         CSTAMP_C(6);                                // compute wave 0 past B1
 
         float hx0 = 0.0f, hy0 = 0.0f, hz0 = 0.0f;  // H0: position of this lane's row
@@ -322,6 +332,9 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                     if ((seen & (seen - 1u)) == 0u) timeout[1] = tag_base | 1u;
                     else timeout[2] = 1u;
                 }
+#ifdef C3D_STAMPS
+                if (stamper) g_pstamps[3] = __builtin_amdgcn_s_memrealtime();
+#endif
             } else if (solo) {
                 // one workgroup owns the replica: new positions and tile sums go straight back into LDS
                 if (lane < RW && hrow < NPAD) { xs[hrow] = xn; ys[hrow] = yn; zs[hrow] = zn; }
@@ -379,6 +392,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 
 #ifdef C3D_STAMPS
 hipError_t read_cluster_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamps), sizeof(unsigned long long) * 64 * 8); }
+hipError_t read_cluster_pstamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * 8); }
 #endif
 
 // ---- host side ---------------------------------------------------------------------------------------
