@@ -657,3 +657,36 @@ def test_cluster_placement_mismatch_switches_to_the_slot_counters(solver):
         assert np.array_equal(xa, xc) and np.array_equal(ea, ec)
     finally:
         solver.set_option("cluster_static_placement", 1)
+
+
+@pytest.mark.parametrize("n", [65, 70, 72, 73, 129, 136, 137, 199, 200, 256, 257, 263, 264, 265, 328, 391, 455, 519, 520, 584, 704, 711, 712, 775, 1000, 1024])
+def test_column_layouts_are_bit_identical_across_launch_forms(solver, O, n):
+    """Every shape of the pair loop's column layout (DevModel wl / nleft: last block 1..4 columns per lane, 0..8 left-over
+    columns, 1..4 blocks) on synthetic matrices: the cluster kernel and the per-step kernel end a short anneal (FIRE, hot MD,
+    cooling MD, FIRE) in the same bits, and the forces hook agrees with the oracle.  n = 64 k + r walks r = 0, 1, 7, 8, 9 at
+    several k; 455 is the headline size (256 + 64 x 3 + 7)."""
+    from chromosome3d_amd import default_model, make_stages, pipeline
+    from tests.util import synthetic_if
+    IF, _ = synthetic_if(n, seed=n)
+    m = default_model()
+    stages = [(2, 12, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 14, 0.003, 0.4, 0.003, 0.9, 2000.0), (1, 12, 0.005, 1.0, 0.05, 1.0, 1500.0),
+              (2, 10, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    out = {}
+    for resident in (0, 1):
+        solver.set_model(m)
+        d10 = pipeline.IF2dist_new(solver, IF)
+        solver.set_schedule(make_stages(stages))
+        solver.set_option("resident", resident)
+        solver.init_replicas(5, 82364, 0)
+        if resident == 0:
+            x0 = solver.coords()
+            F, _ = solver.eval(1.0, 1.0, 0.85)
+            Fo, _ = O.energy_force(oracle_model_from(m, n), d10, x0[0].astype(np.float64), *_f32(1.0, 1.0, 0.85))
+            assert _force_close(F[0], Fo).all(), (n, np.abs(F[0] - Fo).max(), np.abs(Fo).max())
+        assert solver.run_steps(10 ** 6) == 48
+        out[resident] = (solver.coords(), solver.velocities(), solver.stat("last_path"), solver.step_kernel_name)
+    solver.set_option("resident", -1)
+    assert out[0][2] == 0, out[0][3]
+    # beyond 768 padded beads the planner has no cluster geometry and the resident request falls to the per-step kernel
+    assert out[1][2] == (2 if n <= 768 else 0), (n, out[1][3])
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), (n, out[1][3])
