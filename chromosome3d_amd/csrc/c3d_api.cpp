@@ -135,6 +135,7 @@ struct c3d_ctx {
     int resident_skip = 0;                 // ranges left to run step by step before a multi-step launch is tried again
     int resident_backoff = 0;              // doubles with every abandoned launch, back to 0 after a good one
     int num_cus = 0, num_xcc = 0;
+    int cluster_late = -1;                 // measurement knob: 0 = the tile sums always travel with the rows; -1 = planner's choice
     int cluster_geom = 0;                  // measurement knob: 100 CW + 10 RPW + helpers forces that cluster geometry (0 = planner's choice)
     bool inject_misplaced = false;         // test hook: workgroup 0 of the next cluster launch reports a wrong XCD
     bool static_place = true;              // cluster launches number the workgroups of an XCD as blockIdx / 8 (verified in the kernel)
@@ -784,6 +785,7 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
     if (!strcmp(key, "cluster_static_placement")) { c->static_place = value != 0; c->inject_misplaced = value == 2; return C3D_OK; }   // 0: per-XCD atomic slot counters; 2: test hook
     if (!strcmp(key, "cluster_inject_incomplete")) { c->inject_incomplete = value != 0; return C3D_OK; }   // test hook
     if (!strcmp(key, "cluster_num_xcc")) { c->num_xcc = (int)value; free_replica_buffers(c); return C3D_OK; }   // test hook: pretend a partitioned device
+    if (!strcmp(key, "cluster_late_tiles")) { c->cluster_late = value != 0 ? -1 : 0; free_replica_buffers(c); return C3D_OK; }   // measurement knob: 0 = never; before c3d_init_replicas
     if (!strcmp(key, "cluster_geometry")) {  // measurement knob: 100 CW + 10 RPW + helpers (0 = planner); before c3d_init_replicas
         if (value < 0 || value > 1699) return fail(C3D_ERR_INVALID, "cluster_geometry = 100 compute waves + 10 rows per wave + helper waves");
         c->cluster_geom = (int)value;
@@ -944,7 +946,7 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 HIP_TRY(hipMalloc(&c->d_sym_scratch, sizeof(float) * c3d::sym_scratch_floats(m)));
             }
-            c->cl_ok = c3d::cluster_plan(m, c->num_cus, c->num_xcc, c->cluster_geom, &c->cl_plan);
+            c->cl_ok = c3d::cluster_plan(m, c->num_cus, c->num_xcc, c->cluster_geom, c->cluster_late, &c->cl_plan);
             if (c->cl_ok) {
                 c->cl_plan.device = c->device;
                 c->crec_bytes = c3d::cluster_record_bytes(m, c->cl_plan);
@@ -1215,6 +1217,7 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     else if (!strcmp(key, "last_path")) *value = (double)c->last_path;
     else if (!strcmp(key, "cluster_parts")) *value = c->cl_ok ? (double)c->cl_plan.parts : 0.0;
     else if (!strcmp(key, "cluster_rows_per_wave")) *value = c->cl_ok ? (double)c->cl_plan.rpw : 0.0;
+    else if (!strcmp(key, "cluster_late_tiles")) *value = c->cl_ok ? (double)c->cl_plan.late_tiles : 0.0;
     else if (!strcmp(key, "cluster_compute_waves")) *value = c->cl_ok ? (double)c->cl_plan.cw : 0.0;
     else if (!strcmp(key, "cluster_helper_waves")) *value = c->cl_ok ? (double)c->cl_plan.helpers : 0.0;
     else if (!strcmp(key, "cluster_wgs_per_cu")) *value = c->cl_ok ? (double)c->cl_plan.wgs_per_cu : 0.0;
@@ -1230,7 +1233,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     const c3d::DevModel m = dev_model(c);
     const char* gen = (general_tail(m) || c->zero_weight) ? "true" : "false";
     const char* rs1 = (!general_tail(m) && m.rs == 1.0f) ? "true" : "false";
-    if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %d>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, m.wl);
+    if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %d, %s>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, m.wl, c->cl_plan.late_tiles ? "true" : "false");
     else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);
     else if (c->precision == 64) snprintf(buf, sizeof(buf), "c3d::k64_force");
     else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d, %s>", m.noe_pot, gen, m.rpw, (m.wl == 4 && m.nleft == 0) ? "false" : "true");

@@ -56,7 +56,7 @@ __device__ unsigned long long g_pstamps[8];
 #define CSTAMP_C(k) do { } while (0)
 #endif
 
-template <int POT, int RPW, int NB, int WL>
+template <int POT, int RPW, int NB, int WL, bool LATE>
 __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const AnnealIO io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
     const StepRun* __restrict__ runs, const int run0, const int skip0, const int nsteps, const unsigned tag_base,
@@ -118,10 +118,21 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const int hrow = wg_row0 + lane;              // H0: the row of this lane
     const bool hfin = is_h0 && lane < RW && hrow < m.n;
 #define C3D_HROW_INDEX const size_t ix = roff + hrow, iy = ix + NPAD, iz = iy + NPAD   /* formed where used: H0 only */
-    // units of one (parity, replica): row r at r, tile t at NPAD + 2 t and + 1; only real rows and tiles travel
+    // units of one (parity, replica): row r at r, tile t at NPAD + 2 t and + 1; only real rows and tiles travel.  The ROW units gate
+    // the next step (gathered into LDS before B1).  The TILE units are wanted by H0 alone, for the step scalars it forms while the
+    // compute waves already run, and travel in one of two ways (a template parameter: as a run-time switch the two forms cost the
+    // short-loop problems 7 % — H0's chain is their critical path and every extra branch and SGPR reload is on it; cluster_plan chooses):
+    //   LATE        H0 fetches them itself after B1 (tile lane + 64 k into lane's registers); H0 publishes them after B3, while the
+    //               other waves already gather rows: the tile sums and their L2 round trip are off the critical path of a step, but
+    //               H0's scalars are ready ~0.35 us later (0.76 us into the step) — wins where the pair loop is longer than that
+    //   otherwise   they gate B1 with the rows (every thread gathers its share of rows + tiles; B3 follows H0's last store)
     constexpr int rec_stride = NPAD + NPAD / 4;
-    const int units = m.n + 2 * m.ntiles;
-    const int ku = (units + nthreads - 1) / nthreads;
+    constexpr int KT = (MAXT + 63) / 64;          // tiles per H0 lane
+    constexpr bool late = LATE;
+    const int gthreads = late ? nthreads - 64 : nthreads;         // gathering threads (late: all but H0)
+    const int gtid = late ? tid - 64 : tid;
+    const int units = late ? m.n : m.n + 2 * m.ntiles;
+    const int ku = (units + gthreads - 1) / gthreads;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, (int)(sizeof(u32x4) * 2 * m.nrep_g * rec_stride), 0x00020000);
 
     // ---- prologue: everything that stays for the whole launch --------------------------------------
@@ -173,13 +184,13 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         if (hfin) { C3D_HROW_INDEX; vcx = vin[ix]; vcy = vin[iy]; vcz = vin[iz]; }
         st = io.sin[rep];
     }
-    // gather bookkeeping: unit u = tid + nthreads k is unit (u & 1) of row (u >> 1) % RW of part (u >> 1) / RW:
-    // unit 0 = {x, y}, unit 1 = {z, s}; s = word (row & 7) of the tile's four sums where row & 7 < 4
-    int gsrc[KUMAX], gda[KUMAX], gdb[KUMAX], gdc[KUMAX];      // unit index inside the record; float offsets into smem
+    // gather bookkeeping: gathering thread g takes units g, g + gthreads, ...: row u -> {x, y, z} of bead u; tile unit j = 2 t + h ->
+    // three sums (h = 0) or the fourth (h = 1) of tile t; float offsets into smem, words nobody wants go to `dump`
+    int gsrc[KUMAX], gda[KUMAX], gdb[KUMAX], gdc[KUMAX];
     const int dump_off = (int)(dump - smem);
 #pragma unroll
     for (int k = 0; k < KUMAX; ++k) {
-        const int u = min(tid + nthreads * k, units - 1);
+        const int u = min(max(gtid + gthreads * k, 0), units - 1);
         int src, da, db = dump_off, dc = dump_off;
         if (u < m.n) { src = u; da = u; db = NPAD + u; dc = 2 * NPAD + u; }
         else {
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             if ((j & 1) == 0) { da = 3 * NPAD + 4 * t; db = da + 1; dc = da + 2; }
             else da = 3 * NPAD + 4 * t + 3;
         }
-        if (tid + nthreads * k >= units) da = db = dc = dump_off;
+        if (gtid < 0 || gtid + gthreads * k >= units) da = db = dc = dump_off;
         gsrc[k] = src; gda[k] = da; gdb[k] = db; gdc[k] = dc;
     }
 
@@ -236,6 +247,37 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             if (p.kind != 2) { st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0; }
             float4 psum = make_float4(0, 0, 0, 0);
             if (needs_partials) {
+                if (late && !solo && s > 0) {
+                    // the tile sums the replica's parts published in the previous step's tail (tag and parity of THIS step's input);
+                    // nobody else reads ps.  Same bound and same way out as the row gather below.
+                    const unsigned tagp = tag_base + (unsigned)s;
+                    const int basep = ((s & 1) * m.nrep_g + lrep) * rec_stride + NPAD;
+                    u32x4 a[KT], b[KT];
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool ok = true;
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < KT; ++k) {
+                            const int t = min(lane + 64 * k, m.ntiles - 1);
+                            a[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (basep + 2 * t) * 16, 0, 16);
+                            b[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (basep + 2 * t + 1) * 16, 0, 16);
+                        }
+#pragma unroll
+                        for (int k = 0; k < KT; ++k) ok &= a[k].x == tagp && b[k].x == tagp;
+                        if (__all(ok)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        ++spins;
+                        if (spins > (1u << 18) || ((spins & 1023u) == 0 && *timeout != 0u)) {
+                            if (lane == 0) *timeout = 1u;
+                            return;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KT; ++k)
+                        if (lane + 64 * k < m.ntiles)
+                            reinterpret_cast<float4*>(ps)[lane + 64 * k] = make_float4(__uint_as_float(a[k].y), __uint_as_float(a[k].z), __uint_as_float(a[k].w), __uint_as_float(b[k].y));
+                }
                 for (int t = lane; t < m.ntiles; t += 64) {
                     const float4 q = reinterpret_cast<const float4*>(ps)[t];
                     psum.x += q.x; psum.y += q.y; psum.z += q.z; psum.w += q.w;
@@ -306,12 +348,15 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             } else {
                 xn = hx0; yn = hy0; zn = hz0;       // padding row (one-workgroup replicas write it back as it is)
             }
+            // B3 (see the other roles below): the rows are out; what follows here — tile sums, their two units — is wanted by the
+            // H0s of the replica only, well after the next step has started, and runs while the other waves gather rows
+            if (late && !last && !solo) { CSTAMP(4); __builtin_amdgcn_s_barrier(); }      // bare: no wait for the stores' acknowledgement
             // tile sums, the tree of tile_sum8 over eight consecutive lanes: lane 8 t ends with tile t's four sums
             float4 t = q;
             t.x += dpp_mov<0xB1>(t.x); t.y += dpp_mov<0xB1>(t.y); t.z += dpp_mov<0xB1>(t.z); t.w += dpp_mov<0xB1>(t.w);
             t.x += dpp_mov<0x4E>(t.x); t.y += dpp_mov<0x4E>(t.y); t.z += dpp_mov<0x4E>(t.z); t.w += dpp_mov<0x4E>(t.w);
             t.x += dpp_mov<0x12C>(t.x); t.y += dpp_mov<0x12C>(t.y); t.z += dpp_mov<0x12C>(t.z); t.w += dpp_mov<0x12C>(t.w);   // row_ror:12 = lane + 4
-            CSTAMP(3);                              // H0: row update + tile sums done
+            CSTAMP(3);                              // H0: tile sums done
             if (last) {                             // hand the state back to the ordinary buffers
                 if (hfin) {
                     C3D_HROW_INDEX;
@@ -335,7 +380,9 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 #ifdef C3D_STAMPS
                 if (stamper) g_pstamps[3] = __builtin_amdgcn_s_memrealtime();
 #endif
-            } else if (solo) {
+                return;
+            }
+            if (solo) {
                 // one workgroup owns the replica: new positions and tile sums go straight back into LDS
                 if (lane < RW && hrow < NPAD) { xs[hrow] = xn; ys[hrow] = yn; zs[hrow] = zn; }
                 if ((lane & 7) == 0 && lane < RW) reinterpret_cast<float4*>(ps)[lane >> 3] = t;
@@ -348,15 +395,20 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 __builtin_amdgcn_raw_buffer_store_b128(o0, rsrc, u0 * 16, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, rsrc, (u0 + 1) * 16, 0, 0);
             }
+            CSTAMP(5);                              // H0: tile units stored
+            if (solo || late) continue;             // late: H0 has passed B3 and gathers nothing
         }
-        if (last) return;
-        if (solo) continue;
-        CSTAMP(4);                                  // H0: record stored
-        // B3: nobody polls before this workgroup's own record is out: no gather can finish earlier than that, and the
-        // spinning waves cost H0 issue slots (measured: 4.43 us per step with it, 4.53 without)
-        __syncthreads();
-        // ---- gather the replica's records of step s+1 into LDS: re-read until every tag matches ----------
         {
+            if (last) return;
+            if (solo) continue;
+            // B3: nobody polls before this workgroup's own rows are out: no gather can finish earlier than that, and the
+            // spinning waves cost H0 issue slots (measured: 4.43 us per step with it, 4.53 without).  A timing device only — no LDS or
+            // global access is ordered by it — hence the bare instruction: __syncthreads() would hold H0 until its stores are
+            // acknowledged (~0.2 us) before anybody may look for them
+            __builtin_amdgcn_s_barrier();
+            // ---- gather the replica's units of step s+1 into LDS: re-read until every tag matches ----------
+            // (one sweep at a time, no pause before the first: two sweeps in flight did not help, and every 64-clock pause before the
+            //  first sweep adds its own length to the step — the workgroups of a replica run in lock-step, the first sweep is the one)
             u32x4 v[KUMAX];
             unsigned spins = 0;
             for (;;) {
@@ -377,7 +429,6 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                     return;
                 }
             }
-            CSTAMP(5);                              // H0's gather complete
 #pragma unroll
             for (int k = 0; k < KUMAX; ++k)
                 if (k < ku) { smem[gda[k]] = __uint_as_float(v[k].y); smem[gdb[k]] = __uint_as_float(v[k].z); smem[gdc[k]] = __uint_as_float(v[k].w); }
@@ -401,7 +452,12 @@ hipError_t read_cluster_pstamps(unsigned long long* out) { return hipMemcpyFromS
 // Among the geometries that fit, the cheapest by an instruction-count model of one step (VALU issue is the limiter):
 //   per SIMD: ceil(CW / 4) compute waves x (RPW rows x NB blocks x 4 columns x 15 + 60) wave-instructions,
 //   + H0's serial tail (~200) + the hand-off (~570 instruction-times = 0.8 us) unless P == 1.
-bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, ClusterPlan* plan) {
+// Tile sums late (H0 fetches them after B1, LATE = true) where the pair loop of a compute wave — rows x column slots — outlasts
+// H0's later scalars; measured on 13 problems, N = 76 .. 455 (profiles/r03_late_tiles_ab.txt).  Shipped potential only: every
+// (geometry, LATE) pair is one more kernel to compile.
+constexpr bool cluster_late_ok(int pot, int rpw, int nb, int wl) { return pot == 3 && rpw * (4 * (nb - 1) + wl) >= 6; }
+
+bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, int forced_late, ClusterPlan* plan) {
     // the placement arithmetic (replica r on XCD r % 8, XCC_ID & 7) is written for the 8 XCDs of an unpartitioned MI355X:
     // on a partitioned or CU-masked device the cluster kernel is not used at all
     if (m.npad > 1024 || num_xcc != 8 || num_cus < 8 || num_cus % 8) return false;
@@ -428,7 +484,9 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
         if (per_xcd * P > cus_per_xcd * wpc) continue;
         const int threads = (cw + nh) * 64;
         const int kumax = nb > 2 ? 3 : 2;
-        if (m.n + 2 * ((m.n + 7) / 8) > threads * kumax) continue;      // gather: units per thread
+        // tile sums late (H0 fetches them after B1) where the pair loop outlasts H0's later scalars: rows x column slots of a compute wave
+        const int late = P > 1 && forced_late != 0 && cluster_late_ok(m.noe_pot, rpw, nb, m.wl);
+        if ((late ? m.n : m.n + 2 * ((m.n + 7) / 8)) > (late ? threads - 64 : threads) * kumax) continue;      // gather: units per thread
         // coordinates, sums, row buffers + the compute waves' NOE weights
         size_t lds = sizeof(float) * (3 * m.npad + 4 * (m.npad / 8) + 9 * 64 + 24 * 64 + 16) + (size_t)cw * rpw * nb * 64 * 16;
         if (wpc == 1) { if (lds < 84 * 1024) lds = 84 * 1024; }    // more than half of a CU's 160 KB: one workgroup per CU
@@ -444,6 +502,7 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
             plan->rpw = rpw; plan->cw = cw; plan->helpers = nh; plan->wgs_per_cu = wpc; plan->parts = P; plan->per_xcd = per_xcd;
             plan->grid = num_cus * wpc; plan->threads = threads; plan->units = 2 * rw; plan->device = 0; plan->lds = lds;
             plan->expected = (unsigned)(m.nrep_g * P);
+            plan->late_tiles = late;
         }
     }
     return found;
@@ -452,7 +511,7 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
 // two parities x replicas x (one 16-byte unit per row + two per 8-row tile)
 size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl) { (void)pl; return (size_t)2 * m.nrep_g * (m.npad + m.npad / 4) * 16; }
 
-template <int POT, int RPW, int NB, int WL>
+template <int POT, int RPW, int NB, int WL, bool LATE>
 static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                              const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                              hipStream_t s) {
@@ -461,15 +520,15 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
     static std::atomic<bool> attr_set[64];
     const int dev = pl.device & 63;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, WL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, WL, LATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev].store(true, std::memory_order_release);
     }
     if (pl.t0 && pl.t1)
-        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, WL>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
+        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
                               reinterpret_cast<u32x4*>(rec), runs, run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, pl.static_place, m, fp);
     else
-        hipLaunchKernelGGL((k_cluster<POT, RPW, NB, WL>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
+        hipLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
                            run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, pl.static_place, m, fp);
     return hipGetLastError();
 }
@@ -477,13 +536,21 @@ template <int POT>
 static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                                const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                                hipStream_t s) {
+#define C3D_GO(R, B, W)                                                                                                 \
+    do {                                                                                                                \
+        if constexpr (cluster_late_ok(POT, R, B, W)) {                                                                  \
+            if (pl.late_tiles) return cluster_go<POT, R, B, W, true>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
+        }                                                                                                               \
+        if (pl.late_tiles) return hipErrorInvalidValue;                                                                 \
+        return cluster_go<POT, R, B, W, false>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
+    } while (0)
 #define C3D_CL(R, B)                                                                                                    \
     if (pl.rpw == R && m.npad == 256 * B) {                                                                             \
-        if (m.wl == 4) return cluster_go<POT, R, B, 4>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
+        if (m.wl == 4) C3D_GO(R, B, 4);                                                                                 \
         if constexpr (POT == 3) {   /* narrower last blocks: the shipped potential only (cluster_plan refuses the others) */      \
-            if (m.wl == 3) return cluster_go<POT, R, B, 3>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
-            if (m.wl == 2) return cluster_go<POT, R, B, 2>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
-            if (m.wl == 1) return cluster_go<POT, R, B, 1>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s); \
+            if (m.wl == 3) C3D_GO(R, B, 3);                                                                             \
+            if (m.wl == 2) C3D_GO(R, B, 2);                                                                             \
+            if (m.wl == 1) C3D_GO(R, B, 1);                                                                             \
         }                                                                                                               \
         return hipErrorInvalidValue;                                                                                    \
     }
@@ -492,6 +559,7 @@ static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const Clust
     C3D_CL(3, 1); C3D_CL(3, 2);
     C3D_CL(4, 1); C3D_CL(4, 2);
 #undef C3D_CL
+#undef C3D_GO
     return hipErrorInvalidValue;
 }
 

@@ -111,6 +111,10 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *   cluster         0: never use the cluster kernel (test knob)
  *   cluster_geometry  100 x compute waves + 10 x rows per wave + helper waves (e.g. 1244): force that geometry of the cluster
  *                   kernel instead of the planner's choice (measurement knob; 0 = planner); before c3d_init_replicas
+ *   cluster_late_tiles  1 (default) / 0: how the per-tile sums of a step reach the wave that needs them in the cluster kernel —
+ *                   1: where the planner finds the pair loop long enough, that wave fetches them after the next step has
+ *                   started (off the critical path); 0: always gathered with the rows before it starts.  Same bits either way
+ *                   (measurement knob); before c3d_init_replicas
  *   narrow_columns  1 (default) / 0: column layout of the pair loop — the lanes of the last 256-column block own 1..4 columns each and
  *                   up to 8 columns behind it are summed separately (N = 455: 7 column slots per row instead of 8); 0 = four
  *                   columns per lane everywhere (round 2's layout).  The two layouts sum in different orders: results agree to
@@ -163,7 +167,7 @@ int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* lau
  * "cluster_launches", "resident_fallbacks" (multi-step launches abandoned for the per-step path), "cluster_incomplete"
  * (those of them that ended without every (replica, part) workgroup reporting), "cluster_static_placement",
  * "cluster_placement_mismatches", "num_xcc", "last_path"
- * (0 per-step, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "cluster_compute_waves", "replica_groups",
+ * (0 per-step, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "cluster_late_tiles", "cluster_compute_waves", "replica_groups",
  * "k1_recomputed" (elements of the last c3d_set_if_matrix that sat within 1e-10 of a "%.1f" rounding tie and were redone
  * on the host in the reference's operation order), "k1_patched" (how many of those changed, since c3d_create),
  * "rms_force" (largest RMS force component over the replicas at the last minimiser step: the quantity c3d_run holds

@@ -690,3 +690,31 @@ def test_column_layouts_are_bit_identical_across_launch_forms(solver, O, n):
     # beyond 768 padded beads the planner has no cluster geometry and the resident request falls to the per-step kernel
     assert out[1][2] == (2 if n <= 768 else 0), (n, out[1][3])
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), (n, out[1][3])
+
+
+@pytest.mark.parametrize("cid,nrep", [("chr1_500kb", 20), ("chr1_500kb", 7), ("chr4_1mb", 20)])
+def test_tile_sums_fetched_late_or_gathered_with_the_rows_end_in_the_same_bits(solver, cid, nrep):
+    """The two hand-off forms of the cluster kernel (template parameter LATE, chosen by cluster_plan; option cluster_late_tiles = 0
+    forbids the late form): the per-tile sums reach H0 after the next step has started, or gate it together with the rows.
+    Same arithmetic, same bits — a short anneal through every step kind, against each other and against the per-step kernel."""
+    from chromosome3d_amd import default_model, make_stages, pipeline
+    IF = load_if(cid)
+    stages = [(2, 30, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 40, 0.003, 0.4, 0.003, 0.9, 2000.0), (1, 36, 0.005, 1.0, 0.05, 1.0, 1500.0),
+              (2, 30, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    out = {}
+    for mode in ("late", "rows", "per-step"):
+        solver.set_model(default_model())
+        pipeline.IF2dist_new(solver, IF)
+        solver.set_schedule(make_stages(stages))
+        solver.set_option("resident", 0 if mode == "per-step" else 1)
+        solver.set_option("cluster_late_tiles", 0 if mode == "rows" else 1)
+        solver.init_replicas(nrep, 82364, 0)
+        assert solver.run_steps(10 ** 6) == 136
+        out[mode] = (solver.coords(), solver.velocities(), solver.step_kernel_name, solver.stat("cluster_late_tiles"))
+    solver.set_option("resident", -1)
+    solver.set_option("cluster_late_tiles", 1)
+    assert out["late"][2].endswith(", true>") and out["late"][3] == 1, out["late"][2:]
+    assert out["rows"][2].endswith(", false>") and out["rows"][3] == 0, out["rows"][2:]
+    assert "k_step" in out["per-step"][2]
+    for mode in ("rows", "per-step"):
+        assert np.array_equal(out["late"][0], out[mode][0]) and np.array_equal(out["late"][1], out[mode][1]), mode

@@ -12,8 +12,8 @@ import numpy as np
 s = Solver(0)
 L = lib.load()
 L.c3d_debug_cluster_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
-names = ["H0 scalars done", "H0 past B2 (compute waves done)", "H0 row update done", "H0 record stored", "H0 gather complete",
-         "next step starts", "compute wave 0 starts", "compute wave 0 done"]
+names = ["H0 tile units fetched, scalars done", "H0 past B2 (compute waves done)", "H0 tile sums done", "H0 rows updated and stored (B3 next)",
+         "H0 tile units stored", "next step starts", "compute wave 0 starts", "compute wave 0 done"]
 cases = [a.split(":") for a in sys.argv[1:]] or [("chr1_500kb", "20"), ("chr1_500kb", "8"), ("chr4_1mb", "20"), ("chr21_1mb", "20")]
 for cid, nrep in cases:
     nrep = int(nrep)
@@ -35,5 +35,5 @@ for cid, nrep in cases:
         med = np.median(rel[2:-2], axis=0)
         print(f"{cid} {kind} nrep={nrep} parts={s.stat('cluster_parts'):.0f} cw={s.stat('cluster_compute_waves'):.0f} rpw={s.stat('cluster_rows_per_wave'):.0f}: "
               f"{1e3 * ms / K:.2f} us/step")
-        for n_, v in zip(names, med):
+        for v, n_ in sorted(zip(med, names)):
             print(f"      {v:6.2f} us  {n_}")
