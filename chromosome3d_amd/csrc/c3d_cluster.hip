@@ -58,10 +58,13 @@ __device__ unsigned long long g_pstamps[8];
 
 template <int POT, int RPW, int NB, int WL, bool LATE>
 __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
-    const AnnealIO io, const float* __restrict__ tgt, u32x4* __restrict__ rec,
-    const StepRun* __restrict__ runs, const int run0, const int skip0, const int nsteps, const unsigned tag_base,
-    volatile unsigned* __restrict__ timeout, unsigned* __restrict__ claim, const int P, const int CW, const int NH,
-    const unsigned expected, const int static_place, const DevModel m, const DevFire fp) {
+    // argument order: the first 16 dwords arrive in SGPRs with the wave (kernarg preload, Makefile), the rest after a ~0.7 us fetch —
+    // what the placement and the first loads of the prologue need comes first
+    // (14 dwords here: 16 user SGPRs less the kernarg pointer)
+    const float* __restrict__ tgt, unsigned* __restrict__ claim, const StepRun* __restrict__ runs, const int P, const int CW, const int NH,
+    const int static_place, const int nbeads, const int run0, const int skip0, const int nsteps,
+    const unsigned tag_base, u32x4* __restrict__ rec, volatile unsigned* __restrict__ timeout, const unsigned expected,
+    const AnnealIO io, const DevModel m, const DevFire fp) {
     constexpr int NPAD = 256 * NB;
     constexpr int MAXT = NPAD / 8;
     constexpr int KUMAX = NB > 2 ? 3 : 2;         // gather loads per thread: P * 2 RW <= threads * KUMAX
@@ -103,18 +106,45 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         slot = *s_slot;
     }
     const int lrep = xcc + 8 * (slot / P), part = slot % P;       // replica index inside this launch's group
-    if (lrep >= m.nrep_g) return;                 // this CU has nothing to do
-    const int rep = m.rep_base + lrep;
-    const bool solo = P == 1;
+#ifdef C3D_STAMPS
+    const unsigned long long t_placed = __builtin_amdgcn_s_memrealtime();
+#endif
     // waves 0 .. NH-1 are the helpers (the OLDEST waves of their SIMDs: instruction arbitration favours age, and the
     // helpers' chains are the serial part of a step), waves NH .. NH+CW-1 compute
     const bool is_compute = wave >= NH, is_h0 = wave == 0;
     const int cwave = wave - NH;                  // compute wave index
+    const int wg_row0 = part * RW;
+    const int row0 = wg_row0 + cwave * RPW;       // compute waves: first row of the wave
+    // The long loads of the prologue leave first, from the arguments that came with the wave: the first run's parameters (a scalar
+    // load nobody would otherwise ask for before the first barrier) and this wave's rows of the target matrix, 96 KB per workgroup
+    // (the same for every replica: before it is known whether this CU has work at all)
+    const StepRun first_run = runs[run0];
+    float4 traw[RPW][NB];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            float4 t = make_float4(0, 0, 0, 0);
+            if (is_compute) {
+                const float* trow = tgt + (size_t)min(row0 + r, nbeads - 1) * NPAD + 256 * jb;
+                if (jb < NB - 1 || WL == 4) t = *reinterpret_cast<const float4*>(trow + 4 * lane);
+                else if constexpr (WL == 3) {       // the last block's lanes own WL columns: one 12-byte load
+                    struct F3 { float a, b, c; };
+                    const F3 q = *reinterpret_cast<const F3*>(trow + 3 * lane);
+                    t = make_float4(q.a, q.b, q.c, 0.0f);
+                } else if constexpr (WL == 2) {
+                    const float2 q = *reinterpret_cast<const float2*>(trow + 2 * lane);
+                    t = make_float4(q.x, q.y, 0.0f, 0.0f);
+                } else t = make_float4(trow[lane], 0.0f, 0.0f, 0.0f);
+            }
+            traw[r][jb] = t;
+        }
+    if (lrep >= m.nrep_g) return;                 // this CU has nothing to do
+    const int rep = m.rep_base + lrep;
+    const bool solo = P == 1;
     if (!is_compute) __builtin_amdgcn_s_setprio(3);
 
     const size_t roff = (size_t)rep * 3 * NPAD;
-    const int wg_row0 = part * RW;
-    const int row0 = wg_row0 + cwave * RPW;       // compute waves: first row of the wave
     const int hrow = wg_row0 + lane;              // H0: the row of this lane
     const bool hfin = is_h0 && lane < RW && hrow < m.n;
 #define C3D_HROW_INDEX const size_t ix = roff + hrow, iy = ix + NPAD, iz = iy + NPAD   /* formed where used: H0 only */
@@ -136,25 +166,23 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, (int)(sizeof(u32x4) * 2 * m.nrep_g * rec_stride), 0x00020000);
 
     // ---- prologue: everything that stays for the whole launch --------------------------------------
-    // per-pair constants of the clamp form (c3d_step_core.h: pair_b = target / rswitch in registers, pair_a = 1 / rswitch where
-    // a restraint exists in wave-private LDS), the same for every step of the launch
-    float4 tv[RPW][NB];
-    float4* const mw = reinterpret_cast<float4*>(dump + 8) + (size_t)(is_compute ? cwave : 0) * (RPW * NB * 64);
+    // this replica's state: issued now (the pointers arrived with the second half of the arguments), consumed below while the
+    // targets are still coming in
+    float vcx = 0.0f, vcy = 0.0f, vcz = 0.0f;     // H0: velocity of this lane's row, carried from step to step
+    FireState st;
+    float4 cin[2], pin4 = make_float4(0, 0, 0, 0);
     {
-        DevStep p0{};
+        const float* xin = io.xin;
+        const float* pin = io.pin;
+        const float* vin = io.vin;
 #pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int jb = 0; jb < NB; ++jb) {
-                float4 t = make_float4(0, 0, 0, 0);
-                if (is_compute) {
-                    const float* trow = tgt + (size_t)min(row0 + r, m.n - 1) * NPAD + 256 * jb;
-                    if (jb < NB - 1 || WL == 4) t = *reinterpret_cast<const float4*>(trow + 4 * lane);
-                    else t = make_float4(trow[WL * lane], WL > 1 ? trow[WL * lane + 1] : 0.0f, WL > 2 ? trow[WL * lane + 2] : 0.0f, 0.0f);   // the last block's lanes own WL columns
-                }
-                tv[r][jb] = pair_b<false>(m, t);
-                if (is_compute) mw[(r * NB + jb) * 64 + lane] = pair_a<false>(m, p0, t);
-            }
+        for (int k = 0; k < 2; ++k) {             // 3 NPAD floats over the workgroup: at most two float4 per thread (3 NPAD <= 8 x 512)
+            const int b = 4 * (tid + k * nthreads);
+            cin[k] = b < 3 * NPAD ? *reinterpret_cast<const float4*>(xin + roff + b) : make_float4(0, 0, 0, 0);
+        }
+        if (tid < m.ntiles) pin4 = reinterpret_cast<const float4*>(pin)[(size_t)rep * m.ntiles + tid];
+        if (hfin) { C3D_HROW_INDEX; vcx = vin[ix]; vcy = vin[iy]; vcz = vin[iz]; }
+        st = io.sin[rep];
     }
     // chain helpers: pair constants of the left-over columns of "their" rows — pass q of helper `wave` covers rows 8 (wave - 1) +
     // 8 (NH - 1) q + (lane >> 3) of the workgroup, lane & 7 = the column; at most 4 passes (RW <= 64, two helpers)
@@ -171,19 +199,34 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             lc[(2 * q) * 64 + lane] = b; lc[(2 * q + 1) * 64 + lane] = a;
         }
     }
-    float vcx = 0.0f, vcy = 0.0f, vcz = 0.0f;     // H0: velocity of this lane's row, carried from step to step
-    FireState st;
-    {
-        const float* xin = io.xin;
-        const float* pin = io.pin;
-        const float* vin = io.vin;
-        for (int b = 4 * tid; b < 3 * NPAD; b += 4 * nthreads)
-            *reinterpret_cast<float4*>(smem + b) = *reinterpret_cast<const float4*>(xin + roff + b);
-        for (int t = tid; t < m.ntiles; t += nthreads)
-            reinterpret_cast<float4*>(ps)[t] = reinterpret_cast<const float4*>(pin)[(size_t)rep * m.ntiles + t];
-        if (hfin) { C3D_HROW_INDEX; vcx = vin[ix]; vcy = vin[iy]; vcz = vin[iz]; }
-        st = io.sin[rep];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int b = 4 * (tid + k * nthreads);
+        if (b < 3 * NPAD) *reinterpret_cast<float4*>(smem + b) = cin[k];
     }
+    if (tid < m.ntiles) reinterpret_cast<float4*>(ps)[tid] = pin4;
+#ifdef C3D_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t_coords = __builtin_amdgcn_s_memrealtime();
+#endif
+    // per-pair constants of the clamp form (c3d_step_core.h: pair_b = target / rswitch in registers, pair_a = 1 / rswitch where
+    // a restraint exists in wave-private LDS), the same for every step of the launch
+    float4 tv[RPW][NB];
+    float4* const mw = reinterpret_cast<float4*>(dump + 8) + (size_t)(is_compute ? cwave : 0) * (RPW * NB * 64);
+    {
+        DevStep p0{};
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+                tv[r][jb] = pair_b<false>(m, traw[r][jb]);
+                if (is_compute) mw[(r * NB + jb) * 64 + lane] = pair_a<false>(m, p0, traw[r][jb]);
+            }
+    }
+#ifdef C3D_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long t_targets = __builtin_amdgcn_s_memrealtime();
+#endif
     // gather bookkeeping: gathering thread g takes units g, g + gthreads, ...: row u -> {x, y, z} of bead u; tile unit j = 2 t + h ->
     // three sums (h = 0) or the fourth (h = 1) of tile t; float offsets into smem, words nobody wants go to `dump`
     int gsrc[KUMAX], gda[KUMAX], gdb[KUMAX], gdc[KUMAX];
@@ -206,7 +249,8 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 #ifdef C3D_STAMPS
     const bool stamper = lrep == 0 && part == 0 && is_h0 && lane == 0;
     const bool cstamper = lrep == 0 && part == 0 && cwave == 0 && lane == 0;
-    if (stamper) { g_pstamps[0] = t_entry; g_pstamps[1] = __builtin_amdgcn_s_memrealtime(); }
+    if (stamper) { g_pstamps[0] = t_entry; g_pstamps[1] = __builtin_amdgcn_s_memrealtime(); g_pstamps[6] = t_placed; }
+    if (cstamper) { g_pstamps[4] = t_targets; g_pstamps[5] = t_coords; }
 #endif
     // One step loop PER ROLE (compute wave, H0, chain helper): the waves of a workgroup keep their role for the whole launch, and
     // written as one loop with role branches inside, every role's registers are live in every other role's code (the compiler
@@ -216,11 +260,16 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     auto role_loop = [&](auto role) {
     constexpr int ROLE = decltype(role)::value;     // 0 compute wave, 1 H0, 2 chain helper
     int s = 0;
+    StepRun cur = first_run;
     for (int run = run0;; ++run) {                  // left by the `return` of the last step
-      const DevStep p = runs[run].p;
-      const int count = runs[run].count;
+      if (run != run0) cur = runs[run];
+      const DevStep p = cur.p;
+      const int count = cur.count;
       const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
       for (int it = run == run0 ? skip0 : 0; it < count; ++it, ++s) {
+#ifdef C3D_STAMPS
+        if (cstamper && s == 0) g_pstamps[7] = __builtin_amdgcn_s_memrealtime();
+#endif
         __syncthreads();                            // B1: xs/ys/zs/ps of this step are in LDS
         CSTAMP(0);                                  // step start (H0 past B1)
 #ifdef C3D_STAMPS
@@ -525,11 +574,11 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
         attr_set[dev].store(true, std::memory_order_release);
     }
     if (pl.t0 && pl.t1)
-        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, io, tgt,
-                              reinterpret_cast<u32x4*>(rec), runs, run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, pl.static_place, m, fp);
+        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, tgt, claim, runs,
+                              pl.parts, pl.cw, pl.helpers, pl.static_place, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);
     else
-        hipLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, io, tgt, reinterpret_cast<u32x4*>(rec), runs,
-                           run0, skip0, nsteps, tag_base, timeout, claim, pl.parts, pl.cw, pl.helpers, pl.expected, pl.static_place, m, fp);
+        hipLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, tgt, claim, runs, pl.parts, pl.cw, pl.helpers,
+                           pl.static_place, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);
     return hipGetLastError();
 }
 template <int POT>

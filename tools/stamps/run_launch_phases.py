@@ -22,11 +22,15 @@ for _ in range(40):
     s.run_steps(K)
     buf = (C.c_ulonglong * 8)()
     L.c3d_debug_cluster_pstamps(buf)
-    t = [0.01 * (buf[k] - buf[0]) for k in range(4)]
+    t = [0.01 * (buf[k] - buf[0]) for k in range(8)]
     rows.append(t + [s.stat("last_kernel_us")])
 m = np.median(np.array(rows), axis=0)
 print(f"{K} steps per launch, chr1_500kb x 20, medians of 40 launches (us since the stamping workgroup's first instruction):")
-print(f"  prologue done            {m[1]:7.2f}")
+print(f"  H0: slot known           {m[6]:7.2f}")
+print(f"  compute wave 0: targets in registers, pair constants in LDS  {m[4]:7.2f}")
+print(f"  compute wave 0: its share of the coordinates in LDS          {m[5]:7.2f}")
+print(f"  compute wave 0 at the first barrier                          {m[7]:7.2f}")
+print(f"  H0: prologue done        {m[1]:7.2f}")
 print(f"  first step starts        {m[2]:7.2f}")
 print(f"  last step finished       {m[3]:7.2f}   -> {(m[3] - m[2]) / K:.3f} us per step")
-print(f"  kernel start-stop events {m[4]:7.2f}   -> {m[4] - m[3]:.2f} us outside the workgroup's own time (dispatch before, drain after)")
+print(f"  kernel start-stop events {m[8]:7.2f}   -> {m[8] - m[3]:.2f} us outside the workgroup's own time (dispatch before, drain after)")
