@@ -374,28 +374,47 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 
         if constexpr (ROLE == 1) {
             // ---- row update, lane k <-> row k of the workgroup ------------------------------------------
+            // One copy of the update per step kind (a run has one kind; the switch is scalar): between B2 and the rows' store every
+            // instruction of this lone wave costs ~5 ns of the step, and written once with the kind tested inside, the path held some
+            // twenty scalar branches and three dependent LDS round trips (the reads sat in different blocks)
             float4 q = make_float4(0, 0, 0, 0);
             float xn = 0.0f, yn = 0.0f, zn = 0.0f;
-            if (hfin) {
-                float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
-                if (p.kind != 4) {
-                    float sx = fbuf[lane], sy = fbuf[64 + lane], sz = fbuf[128 + lane];
-                    if (m.nleft > 0) { sx += lbuf[lane]; sy += lbuf[64 + lane]; sz += lbuf[128 + lane]; }
-                    Fx = pair_sum_scaled<false>(p, sx) + cbuf[lane];
-                    Fy = pair_sum_scaled<false>(p, sy) + cbuf[64 + lane];
-                    Fz = pair_sum_scaled<false>(p, sz) + cbuf[128 + lane];
+            auto row_update = [&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                DevStep pk = p;
+                pk.kind = K;
+                if (hfin) {
+                    float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
+                    if constexpr (K != 4) {
+                        // nine words, one round trip (lbuf holds nothing where there are no left-over columns: read, not used)
+                        const float sx0 = fbuf[lane], sy0 = fbuf[64 + lane], sz0 = fbuf[128 + lane];
+                        const float lx = lbuf[lane], ly = lbuf[64 + lane], lz = lbuf[128 + lane];
+                        const float cx = cbuf[lane], cy = cbuf[64 + lane], cz = cbuf[128 + lane];
+                        const bool lo = m.nleft > 0;
+                        const float sx = lo ? sx0 + lx : sx0, sy = lo ? sy0 + ly : sy0, sz = lo ? sz0 + lz : sz0;
+                        Fx = pair_sum_scaled<false>(pk, sx) + cx;
+                        Fy = pair_sum_scaled<false>(pk, sy) + cy;
+                        Fz = pair_sum_scaled<false>(pk, sz) + cz;
+                    }
+                    float vx0 = vcx, vy0 = vcy, vz0 = vcz;
+                    if constexpr (K == 3) { vx0 = vy0 = vz0 = 0.0f; }
+                    else if constexpr (K == 4) { C3D_HROW_INDEX; const float* vinit = io.vinit; vx0 = vinit[ix]; vy0 = vinit[iy]; vz0 = vinit[iz]; }
+                    finish_row(m, pk, fp, sc, st, Fx, Fy, Fz, hx0, hy0, hz0, vx0, vy0, vz0, xn, yn, zn, vcx, vcy, vcz, q);
+                    if (!last && !solo) {               // the row's new position leaves at once; the tile sums follow below
+                        u32x4 o;
+                        o.x = tag; o.y = __float_as_uint(xn); o.z = __float_as_uint(yn); o.w = __float_as_uint(zn);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (base + hrow) * 16, 0, 0);     // plain: the line stays in this XCD's L2
+                    }
+                } else {
+                    xn = hx0; yn = hy0; zn = hz0;       // padding row (one-workgroup replicas write it back as it is)
                 }
-                float vx0 = vcx, vy0 = vcy, vz0 = vcz;
-                if (p.kind == 3) { vx0 = vy0 = vz0 = 0.0f; }
-                else if (p.kind == 4) { C3D_HROW_INDEX; const float* vinit = io.vinit; vx0 = vinit[ix]; vy0 = vinit[iy]; vz0 = vinit[iz]; }
-                finish_row(m, p, fp, sc, st, Fx, Fy, Fz, hx0, hy0, hz0, vx0, vy0, vz0, xn, yn, zn, vcx, vcy, vcz, q);
-                if (!last && !solo) {               // the row's new position leaves at once; the tile sums follow below
-                    u32x4 o;
-                    o.x = tag; o.y = __float_as_uint(xn); o.z = __float_as_uint(yn); o.w = __float_as_uint(zn);
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (base + hrow) * 16, 0, 0);     // plain: the line stays in this XCD's L2
-                }
-            } else {
-                xn = hx0; yn = hy0; zn = hz0;       // padding row (one-workgroup replicas write it back as it is)
+            };
+            switch (p.kind) {
+                case 0: row_update(std::integral_constant<int, 0>{}); break;
+                case 1: row_update(std::integral_constant<int, 1>{}); break;
+                case 2: row_update(std::integral_constant<int, 2>{}); break;
+                case 3: row_update(std::integral_constant<int, 3>{}); break;
+                default: row_update(std::integral_constant<int, 4>{}); break;
             }
             // B3 (see the other roles below): the rows are out; what follows here — tile sums, their two units — is wanted by the
             // H0s of the replica only, well after the next step has started, and runs while the other waves gather rows
