@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>
@@ -92,6 +93,7 @@ struct c3d_ctx {
     hipEvent_t kev0 = nullptr, kev1 = nullptr;     // kernel_timing: the multi-step kernel's own start / end
     int kernel_timing = 0;
     double last_kernel_ms = 0;
+    double last_host_launch_us = 0, last_host_sync_us = 0;   // host time inside the launch call / the synchronise call of the last c3d_run_steps (cluster launches)
     int event_timing = 1;                          // 0: no event pair around c3d_run_steps / c3d_run (c3d_last_timing then reports 0 ms)
     bool ev1_recorded = false;                     // the closing event of the timed range already sits behind the last launch
 
@@ -417,12 +419,17 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     pl.static_place = c->static_place ? (c->inject_misplaced ? 2 : 1) : 0;
     c->inject_misplaced = false;
     c->h_tmo[2] = 0;
+    const auto h0 = std::chrono::steady_clock::now();
     hipError_t e = c3d::launch_cluster(m, dev_fire(c), pl, c3d::anneal_io(c->buf, c->parity), c->buf.tgt, c->d_crec, c->d_prog,
                                        c->op_run[c->pc], c->op_skip[c->pc], (int)nops, seq << 20, c->h_tmo_dev,
                                        c->d_claim + c3d_ctx::kClaimWords * seq, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("cluster launch: ") + hipGetErrorString(e));
     if (c->event_timing) HIP_TRY(hipEventRecord(c->ev1, c->stream));    // closes the timed range unless more work follows (end_timing)
+    const auto h1 = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const auto h2 = std::chrono::steady_clock::now();
+    c->last_host_launch_us += std::chrono::duration<double, std::micro>(h1 - h0).count();
+    c->last_host_sync_us += std::chrono::duration<double, std::micro>(h2 - h1).count();
     c->ev1_recorded = true;
     ++c->cluster_launches;
     if (c->kernel_timing) {
@@ -546,7 +553,7 @@ int run_ops(c3d_ctx* c, size_t nops) {
 }
 
 int begin_timing(c3d_ctx* c) {
-    c->last_ms = 0; c->last_kernel_ms = 0; c->last_steps = 0; c->last_launches = 0;
+    c->last_ms = 0; c->last_kernel_ms = 0; c->last_steps = 0; c->last_launches = 0; c->last_host_launch_us = 0; c->last_host_sync_us = 0;
     c->ev1_recorded = false;
     if (c->event_timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
     return C3D_OK;
@@ -1193,6 +1200,8 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     if (!c || !key || !value) return fail(C3D_ERR_INVALID, "c3d_get_stat: null argument");
     if (!strcmp(key, "graph_captures")) *value = (double)c->graph_captures;
     else if (!strcmp(key, "last_kernel_us")) *value = 1e3 * c->last_kernel_ms;
+    else if (!strcmp(key, "last_host_launch_us")) *value = c->last_host_launch_us;
+    else if (!strcmp(key, "last_host_sync_us")) *value = c->last_host_sync_us;
     else if (!strcmp(key, "graph_launches")) *value = (double)c->graph_launches;
     else if (!strcmp(key, "graphs_cached")) *value = (double)c->graphs.size();
     else if (!strcmp(key, "step_launches")) *value = (double)c->step_launches;

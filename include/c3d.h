@@ -167,7 +167,7 @@ int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* lau
  * "cluster_launches", "resident_fallbacks" (multi-step launches abandoned for the per-step path), "cluster_incomplete"
  * (those of them that ended without every (replica, part) workgroup reporting), "cluster_static_placement",
  * "cluster_placement_mismatches", "num_xcc", "last_path"
- * (0 per-step, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "cluster_late_tiles", "cluster_compute_waves", "replica_groups",
+ * (0 per-step, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "cluster_late_tiles", "last_host_launch_us", "last_host_sync_us" (host time inside the launch / synchronise call of the last c3d_run_steps, cluster launches), "cluster_compute_waves", "replica_groups",
  * "k1_recomputed" (elements of the last c3d_set_if_matrix that sat within 1e-10 of a "%.1f" rounding tie and were redone
  * on the host in the reference's operation order), "k1_patched" (how many of those changed, since c3d_create),
  * "rms_force" (largest RMS force component over the replicas at the last minimiser step: the quantity c3d_run holds
