@@ -116,7 +116,7 @@ def chain_stats(x):
     return float(b.mean()), float(b.std()), float(a.mean()), float(a.std()), rg
 
 
-def structure_report(IF, x, e_noe, ref_xyz, ref_rank=1):
+def structure_report(IF, x, e_noe, ref_xyz, ref_rank=1, rows=None):
     """Everything the parity table holds for one matrix: x [M, N, 3] our replicas, e_noe [M], ref_xyz [N, 3] the bundled
     model, ref_rank its rank in the reference's run.  Scoring through the product's pinned host routines
     (spearman_IF_pdb.pl:42-70 = c3d_spearman_if_dist; output_models/similarity.txt = c3d_model_similarity)."""
@@ -133,7 +133,12 @@ def structure_report(IF, x, e_noe, ref_xyz, ref_rank=1):
     # how alike two of OUR replicas are: the scale on which "same structure as the reference's" has to be read
     sim_own = pipeline.model_similarity(x[best], x[int(order[1])]) if M > 1 else (1.0, 0.0)
     ours, ref = chain_stats(x[best]), chain_stats(ref_xyz)
-    return dict(rho=rho, order=order, best=best, matched=matched, rho_best=float(rho[best]), rho_matched=float(rho[matched]),
+    # the reference's own final assessment of a model (chromosome3D.pl:447-485, :581-600 = c3d_assess): restraints satisfied within
+    # the relaxation and the summed violation, of OUR best-ranked model and of the bundled one, on the same contact.tbl rows
+    assess = None
+    if rows is not None:
+        assess = dict(best=pipeline.assess(x[best], rows), ref=pipeline.assess(np.asarray(ref_xyz, dtype=np.float32), rows), R=len(rows[0]))
+    return dict(assess=assess, rho=rho, order=order, best=best, matched=matched, rho_best=float(rho[best]), rho_matched=float(rho[matched]),
                 rho_mean=float(rho.mean()), rho_ref=float(rho_ref), delta=float(rho[best] - rho_ref),
                 delta_matched=float(rho[matched] - rho_ref),
                 ref_percentile=float((rho < rho_ref).mean()),      # fraction of our replicas below the reference's value

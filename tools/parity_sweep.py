@@ -37,27 +37,29 @@ def all_cids():
 
 def solve(s, IF, over, nrep=20, seed=82364, min_steps=3000, embed=0):
     s.set_model(default_model(**over))
-    pipeline.IF2dist_new(s, IF)
+    d10 = pipeline.IF2dist_new(s, IF)
     s.set_schedule(default_schedule(min_steps), default_fire(), 0.0, 250)
     s.init_replicas(nrep, seed, 0)
     if embed:
         s.embed(50)
     s.run()
-    return s.coords(), s.energies()
+    return s.coords(), s.energies(), pipeline.restraints_from_dist10(d10)
 
 
 HEADER = ("| matrix | N | R | rho best | rho rank-matched (rank) | rho mean | rho reference | d best | d matched | ref pct | "
-          "dist-Spearman best / matched / own | dRMSD best / own | bond ours | bond ref | i+2 ours | i+2 ref | Rg ours/ref | ratio | ms |\n"
-          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+          "dist-Spearman best / matched / own | dRMSD best / own | bond ours | bond ref | i+2 ours | i+2 ref | Rg ours/ref | ratio | "
+          "satisfied ours / ref (%) | deviation sum ours / ref | ms |\n"
+          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 
 
 def row(cid, n, R, rep, rank, ms):
     c, cr = rep["chain"], rep["chain_ref"]
     return ("| %-12s | %4d | %6d | %.4f | %.4f (%d) | %.4f | %.4f | %+.4f | %+.4f | %.2f | %.3f / %.3f / %.3f | %.2f / %.2f | "
-            "%.2f±%.2f | %.2f±%.2f | %.2f±%.2f | %.2f±%.2f | %.1f / %.1f | %.3f | %.0f |" % (
+            "%.2f±%.2f | %.2f±%.2f | %.2f±%.2f | %.2f±%.2f | %.1f / %.1f | %.3f | %.1f / %.1f | %.4g / %.4g | %.0f |" % (
                 cid, n, R, rep["rho_best"], rep["rho_matched"], rank, rep["rho_mean"], rep["rho_ref"], rep["delta"], rep["delta_matched"],
                 rep["ref_percentile"], rep["sim_best"][0], rep["sim_matched"][0], rep["sim_own"][0], rep["sim_best"][1], rep["sim_own"][1],
-                c[0], c[1], cr[0], cr[1], c[2], c[3], cr[2], cr[3], c[4], cr[4], rep["rg_ratio"], ms))
+                c[0], c[1], cr[0], cr[1], c[2], c[3], cr[2], cr[3], c[4], cr[4], rep["rg_ratio"],
+                100.0 * rep["assess"]["best"][0] / R, 100.0 * rep["assess"]["ref"][0] / R, rep["assess"]["best"][1], rep["assess"]["ref"][1], ms))
 
 
 def summary(reps):
@@ -65,13 +67,16 @@ def summary(reps):
     rg = np.array([r["rg_ratio"] for r in reps]); sb = np.array([r["sim_best"][0] for r in reps]); so = np.array([r["sim_own"][0] for r in reps])
     bsd = np.array([r["chain"][1] - r["chain_ref"][1] for r in reps]); a2 = np.array([r["chain"][2] - r["chain_ref"][2] for r in reps])
     pct = np.array([r["ref_percentile"] for r in reps])
+    sat = np.array([r["assess"]["best"][0] / r["assess"]["ref"][0] for r in reps]); dev = np.array([r["assess"]["best"][1] / r["assess"]["ref"][1] for r in reps])
     return (f"# {len(d)} matrices: |d best| mean {np.abs(d).mean():.4f} median {np.median(np.abs(d)):.4f} max {np.abs(d).max():.4f}, "
             f"within 0.01: {(np.abs(d) <= 0.01).sum()}, 0.02: {(np.abs(d) <= 0.02).sum()}, 0.03: {(np.abs(d) <= 0.03).sum()}, bias {d.mean():+.4f}; "
             f"rank-matched: mean {np.abs(dm).mean():.4f}, within 0.01: {(np.abs(dm) <= 0.01).sum()}, bias {dm.mean():+.4f}; "
             f"reference inside our replica range (0 < pct < 1): {((pct > 0) & (pct < 1)).sum()}; "
             f"dist-Spearman ours vs bundled: mean {sb.mean():.4f} min {sb.min():.4f} (ours vs ours: mean {so.mean():.4f} min {so.min():.4f}); "
             f"Rg ratio mean {rg.mean():.3f} range {rg.min():.3f}-{rg.max():.3f}, within 2%: {(np.abs(rg - 1) <= 0.02).sum()}; "
-            f"bond sd ours-ref mean {bsd.mean():+.3f}; i+2 mean ours-ref {a2.mean():+.3f}")
+            f"bond sd ours-ref mean {bsd.mean():+.3f}; i+2 mean ours-ref {a2.mean():+.3f}; "
+            f"reference's assessment, ours / bundled: satisfied restraints ratio mean {sat.mean():.3f} range {sat.min():.3f}-{sat.max():.3f}, "
+            f"deviation sum ratio mean {dev.mean():.3f} range {dev.min():.3f}-{dev.max():.3f}")
 
 
 def main():
@@ -94,10 +99,10 @@ def main():
         Xr = load_pdb_xyz(ref[0])
         if len(Xr) != IF.shape[0]:
             continue
-        x, e = solve(s, IF, over, nrep, seed, min_steps, embed)
+        x, e, rows = solve(s, IF, over, nrep, seed, min_steps, embed)
         ms = s.last_timing()[0]
         rank = bundled_rank(ref[0])
-        rep = structure_report(IF, x, e[:, 0], Xr, rank)
+        rep = structure_report(IF, x, e[:, 0], Xr, rank, rows)
         rep["cid"] = cid
         reps.append(rep)
         if dump:
