@@ -205,6 +205,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         if (b < 3 * NPAD) *reinterpret_cast<float4*>(smem + b) = cin[k];
     }
     if (tid < m.ntiles) reinterpret_cast<float4*>(ps)[tid] = pin4;
+    if (tid < 3 * 64) lbuf[tid] = 0.0f;           // H0 reads it every step; written by the helpers only where left-over columns exist
 #ifdef C3D_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long t_coords = __builtin_amdgcn_s_memrealtime();
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 if (hfin) {
                     float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
                     if constexpr (K != 4) {
-                        // nine words, one round trip (lbuf holds nothing where there are no left-over columns: read, not used)
+                        // nine words, one round trip (lbuf stays zero where there are no left-over columns: read, not used)
                         const float sx0 = fbuf[lane], sy0 = fbuf[64 + lane], sz0 = fbuf[128 + lane];
                         const float lx = lbuf[lane], ly = lbuf[64 + lane], lz = lbuf[128 + lane];
                         const float cx = cbuf[lane], cy = cbuf[64 + lane], cz = cbuf[128 + lane];
