@@ -20,6 +20,7 @@ def fuzz(s, seed=1, seconds=60.0, out=print):
         stages = [(2, k[0], 0.0, 1.0, 20.0, 0.5, 0.0), (0, k[1], 0.003, 0.4, 0.003, 0.9, 2000.0), (1, k[2], 0.005, 1.0, 0.05, 1.0, 1500.0),
                   (2, k[3], 0.0, 1.0, 1.0, 0.85, 0.0)]
         res = []
+        fb0, inc0 = s.stat("resident_fallbacks"), s.stat("cluster_incomplete")      # counters since c3d_create
         for resident in (0, 1):
             s.set_model(default_model()); pipeline.IF2dist_new(s, IF)
             s.set_schedule(make_stages(stages)); s.set_option("resident", resident); s.set_option("cluster_late_tiles", late)
@@ -29,7 +30,7 @@ def fuzz(s, seed=1, seconds=60.0, out=print):
                 if s.run_steps(int(rng.integers(1, 50))) == 0:
                     break
                 used.add(s.step_kernel_name)
-            res.append((s.coords(), s.velocities(), used, s.stat("resident_fallbacks"), s.stat("cluster_incomplete")))
+            res.append((s.coords(), s.velocities(), used, s.stat("resident_fallbacks") - fb0, s.stat("cluster_incomplete") - inc0))
         same = np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
         for name in res[1][2]:
             kernels[name] = kernels.get(name, 0) + 1
