@@ -159,8 +159,9 @@ def side_figures(device, IF, model, fire, stages, args, B):
         out["value_f64"] = round(v64, 1)
         out["f64"] = {"value": round(v64, 1), "unit": "replica-steps/s", "steps": did, "us_per_step_device": round(1e3 * dev_ms / did, 3),
                       "frac_f64": round(REPLICAS * B / (1e-3 * dev_ms / did) / 1e9 / HBM_PEAK_GBS, 4), "kernel": s.step_kernel_name,
-                      "note": "option precision=64: k64_force + k64_update per SA step, the oracle's operation order in fp64 (the reference's "
-                              "precision); same B per replica-step, device time from the HIP-event pair on the solver's stream"}
+                      "note": "option precision=64: one k64_step launch per SA step of a replica group (hipGraph replay, two groups on two streams), "
+                              "the oracle's algorithm in fp64 (the reference's precision); same B per replica-step, device time from the HIP-event "
+                              "pair on the solver's stream"}
         out["frac_f64"] = out["f64"]["frac_f64"]
     finally:
         s.close()
@@ -419,7 +420,7 @@ def main():
                                    f"(200 FIRE + 1000 hot MD + 972 cool MD + {MIN_STEPS} FIRE = {L} SA steps)",
                        "replicas_per_gpu": per_rank, "parallelism": f"replica-sharded x{world}",
                        "launch": {2: "one multi-step cluster launch per region", 0: "eager" if args.no_graph else "hipGraph",
-                                  3: "fp64 reference: force + update launch per step"}.get(path, "?")},
+                                  3: "fp64: one k64_step launch per step and replica group, hipGraph"}.get(path, "?")},
             "reps": reps,
             "region_wall_ms": {"median": round(1e3 * wall, 4), "min": round(1e3 * min(walls), 4), "max": round(1e3 * max(walls), 4)},
             "device_ms_per_region": round(dev_ms, 4),

@@ -74,6 +74,10 @@ my $sequence;
 		open my $sq, "<", $file_seq or die "ERROR! cannot read $file_seq: $!\n";
 		my $letters = join "", map { s/\s+//gr } grep { !/^>/ } <$sq>;
 		close $sq;
+		# one-letter residue codes only: the letters end up in <ID>.fasta and name residues, nothing else may ride along
+		# (a '*' stop codon, ';' or '$(...)' must never reach a shell or a file name)
+		die "ERROR! $file_seq: residue codes must be letters A-Z (found '$1')\n" if $letters =~ /([^A-Za-z])/;
+		$letters = uc $letters;
 		$sequence = substr($letters, 0, $L);
 		$sequence .= "M" x ($L - length $sequence);
 	}
@@ -104,7 +108,8 @@ else {
 # the process boundary of the reference, same sentinel protocol (:258-288)
 open my $job, ">", "job.sh" or die $!;
 print $job "#!/bin/bash\necho \"starting c3d_solve..\"\ntouch iam.running\n";
-print $job "\"$solver\" --if \"$ID.txt\" --out . --id \"$ID\" -k $K -a $ALPHA -m $MODELS --seed $SEED --device $DEVICE".(defined $file_seq ? " --seq $sequence" : "")."\n";
+# every string argument single-quoted for the shell; the residue names travel as the file written above, never as text on the line
+print $job shq($solver)." --if ".shq("$ID.txt")." --out . --id ".shq($ID)." -k ".($K+0)." -a ".($ALPHA+0)." -m ".int($MODELS)." --seed ".int($SEED)." --device ".int($DEVICE).(defined $file_seq ? " --seq ".shq("\@$ID.fasta") : "")."\n";
 print $job "if [ -f \"${ID}_${MODELS}.pdb\" ]; then\n   rm -f iam.running\n   echo \"trial structures written.\"\n   exit\nfi\n";
 print $job "echo \"ERROR! Final structures not found!\"\nmv iam.running iam.failed 2>/dev/null || touch iam.failed\n";
 close $job;
@@ -195,6 +200,8 @@ sub shape_pdb {
 	print $o "END\n";
 	close $o;
 }
+# single-quote a string for /bin/sh
+sub shq { my $s = shift; $s =~ s/'/'\\''/g; return "'$s'"; }
 sub first_line_fields { open my $f, "<", shift or die $!; my $l = <$f>; close $f; $l =~ s/^\s+//; my @t = split /\s+/, $l; return scalar @t; }
 sub read_tbl {
 	my @rows;

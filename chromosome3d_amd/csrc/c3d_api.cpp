@@ -110,9 +110,7 @@ struct c3d_ctx {
     int stage_dma = 1;
     int graph_chunk = 256;
     int precision = 32;                    // 64: the fp64 reference step (c3d_f64.hip) instead of the fp32 kernels
-    double *d64_X = nullptr, *d64_V = nullptr, *d64_F = nullptr, *d64_Vinit = nullptr, *d64_L = nullptr;
-    void* d64_fs = nullptr;
-    int32_t* d64_t10 = nullptr;
+    c3d::Buffers64 b64;                    // fp64 state (c3d_f64.hip), double buffered by step parity like the fp32 buffers
     int sym = 0;                           // symmetric-tile step kernels (c3d_sym.hip): 1 on, 0 off (measured slower: DESIGN 7)
     float* d_sym_scratch = nullptr;
     int2* d_sym_tiles = nullptr;
@@ -194,7 +192,8 @@ void free_replica_buffers(c3d_ctx* c) {
     c->crec_bytes = 0; c->cl_ok = false;
     dev_free(c->buf.Vinit); dev_free(c->buf.E); dev_free(c->d_feval);
     dev_free(c->d_sym_scratch); dev_free(c->d_sym_tiles);
-    dev_free(c->d64_X); dev_free(c->d64_V); dev_free(c->d64_F); dev_free(c->d64_Vinit); dev_free(c->d64_L); dev_free(c->d64_fs); dev_free(c->d64_t10);
+    dev_free(c->b64.T); dev_free(c->b64.Vinit);
+    for (int k = 0; k < 2; ++k) { dev_free(c->b64.X[k]); dev_free(c->b64.V[k]); dev_free(c->b64.P[k]); dev_free(c->b64.S[k]); }
     c->have_replicas = false;
 }
 void drop_graphs(c3d_ctx* c) {
@@ -210,11 +209,15 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
     m.rpw = c->rpw;
     m.stage_dma = c->stage_dma;
     m.noe_pot = h.noe_pot; m.ang_mode = h.ang_mode; m.rep_sep = h.rep_sep;
+    m.mexp = h.msoexp == 2 ? 2 : 1;
     m.rs = h.rswitch;
     m.tail_c = h.asym * h.rswitch;
     m.tail_b = (m.tail_c - 2.0f * h.rswitch) * h.rswitch * h.rswitch;
     m.mrs = h.mrswitch; m.nmrs = -h.mrswitch;
     m.inv_rs = 1.0f / h.rswitch; m.nm_rs = -h.mrswitch / h.rswitch;
+    // the shipped lower side (square up to mrswitch, then soft with exponent 2 and no asymptote) has a fast form of its own in
+    // the clamp-form kernels: device potential 4 (pair_term); it needs the upper tail in clamp form too (slope 2 rswitch)
+    if (h.noe_pot == 3 && h.msoexp == 2 && h.masym == 0.0f && m.tail_b == 0.0f && m.tail_c == 2.0f * m.rs) m.noe_pot = 4;
     // column layout of the pair loop (c3d_internal.h): lanes of the last 256-column block own wl consecutive columns, up to 8
     // columns behind it are left over; both follow from n alone, so every launch form sums the same terms in the same order
     {
@@ -227,7 +230,8 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
         m.wl = wl; m.nleft = nleft; m.jl0 = c->npad - 256 + 64 * wl;
     }
     m.mtail_c = h.masym;
-    m.mtail_b = (m.mtail_c - 2.0f * h.mrswitch) * h.mrswitch * h.mrswitch;
+    // lower side beyond mrswitch: dE/dD = mtail_c - mtail_b / D^(mexp + 1), continuous with 2 D at D = mrswitch
+    m.mtail_b = (m.mtail_c - 2.0f * h.mrswitch) * h.mrswitch * h.mrswitch * (m.mexp == 2 ? h.mrswitch : 1.0f);
     m.k_bond2 = 2.0f * h.k_bond; m.b0 = h.b0;
     m.k_ang2 = 2.0f * h.k_ang; m.a0 = h.a0;
     m.acc = c3d::kAccel / h.mass;
@@ -240,7 +244,7 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
 // default tails: the force stays at its value at the switch distance (slope 2 rs above, 2 mrs below for noe_pot 3)
 bool general_tail(const c3d::DevModel& m) {
     if (!(m.tail_b == 0.0f && m.tail_c == 2.0f * m.rs)) return true;
-    return m.noe_pot == 3 && !(m.mtail_b == 0.0f && m.mtail_c == 2.0f * m.mrs);
+    return m.noe_pot == 3 && !(m.mtail_b == 0.0f && m.mtail_c == 2.0f * m.mrs);      // (device potential 4 is a fast form by construction)
 }
 // the kernels of the general form also serve a step whose restraint weight is zero (the clamp form divides by it)
 bool general_step(const c3d::DevModel& m, const c3d::DevStep& p) { return general_tail(m) || p.w_rs == 0.0f; }
@@ -354,6 +358,17 @@ bool use_sym(const c3d_ctx* c) {
 int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
     c3d::DevModel m = dev_model(c);
     group_range(c, g, m.rep_base, m.nrep_g);
+    if (c->precision == 64) {              // the stage's own doubles, not the floats of DevStep
+        const c3d_model& h = c->model;
+        const c3d_stage& st = c->stages[op.stage];
+        const double mh[15] = {h.s_noe, h.rswitch, h.asym, h.masym, h.mrswitch, h.k_bond, h.b0, h.k_ang, h.a0, h.r0_rep, h.k_rep, h.mass, h.fbeta,
+                               (double)h.min_sep, (double)h.msoexp};
+        const double fh[7] = {c->fire.dt_start, c->fire.dt_max, c->fire.f_inc, c->fire.f_dec, c->fire.alpha_start, c->fire.f_alpha, c->fire.max_step};
+        const double sh[6] = {(double)op.p.kind, st.dt, st.w_all, st.w_vdw, st.repel_s, st.t_bath};
+        hipError_t e64 = c3d::launch_step64(m, mh, sh, fh, c->fire.n_min, c->b64, par, c->gstream[g]);
+        if (e64 != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 step launch: ") + hipGetErrorString(e64));
+        return C3D_OK;
+    }
     hipError_t e = use_sym(c) ? c3d::launch_step_sym(m, op.p, dev_fire(c), c->buf, par, c->d_sym_tiles, c->d_sym_scratch, c->gstream[g])
                               : c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, general_step(m, op.p), c->gstream[g]);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
@@ -444,38 +459,12 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     return C3D_OK;
 }
 
-// fp64 reference path: one force launch + one update launch per op on the context's stream; the fp32 buffers of the
-// current parity receive a copy of the state afterwards (read-back, energies, scoring, the minimiser's exit test)
-int run_ops64(c3d_ctx* c, size_t nops) {
-    c->ev1_recorded = false;
-    const c3d::DevModel m = dev_model(c);
-    const c3d_model& h = c->model;
-    const double mh[14] = {h.s_noe, h.rswitch, h.asym, h.masym, h.mrswitch, h.k_bond, h.b0, h.k_ang, h.a0, h.r0_rep, h.k_rep, h.mass, h.fbeta,
-                           (double)h.min_sep};
-    const double fh[7] = {c->fire.dt_start, c->fire.dt_max, c->fire.f_inc, c->fire.f_dec, c->fire.alpha_start, c->fire.f_alpha, c->fire.max_step};
-    for (size_t k = 0; k < nops; ++k) {
-        const Op& op = c->program[c->pc + k];
-        const c3d_stage& st = c->stages[op.stage];
-        const double sh[6] = {(double)op.p.kind, st.dt, st.w_all, st.w_vdw, st.repel_s, st.t_bath};
-        hipError_t e = c3d::launch_step64(m, mh, sh, fh, c->fire.n_min, c->d64_t10, c->d64_X, c->d64_V, c->d64_F, c->d64_Vinit, c->d64_L,
-                                          c->d64_fs, c->stream);
-        if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 step launch: ") + hipGetErrorString(e));
-        if (op.counted) { ++c->steps_done; ++c->last_steps; }
-    }
-    hipError_t e = c3d::launch_export64(m, c->d64_X, c->d64_V, c->d64_L, c->buf.X[c->parity], c->buf.V[c->parity], c->buf.P[c->parity], c->stream);
-    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 export: ") + hipGetErrorString(e));
-    c->last_launches += (long)nops;
-    c->pc += nops;
-    c->last_path = 3;
-    return C3D_OK;
-}
-
 // run program ops [pc, pc + nops): eager or via cached graphs; every replica group advances on its
 // own stream (fork from / join into stream 0 around the call)
 int run_ops(c3d_ctx* c, size_t nops) {
     if (nops == 0) return C3D_OK;
-    if (c->precision == 64) return run_ops64(c, nops);
-    if (c->resident_skip > 0 && c->resident < 1) --c->resident_skip;     // cooling off after an abandoned launch
+    if (c->precision == 64) { }                                           // fp64: the per-step path below (k64_step), never the cluster kernel
+    else if (c->resident_skip > 0 && c->resident < 1) --c->resident_skip;     // cooling off after an abandoned launch
     else if (nops >= (size_t)c->resident_min_ops && nops < ((size_t)1 << 20)) {
         bool ran = false;
         int rc = C3D_OK;
@@ -549,6 +538,12 @@ int run_ops(c3d_ctx* c, size_t nops) {
         HIP_TRY(hipEventRecord(c->gev[g], c->gstream[g]));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->gev[g], 0));
     }
+    if (c->precision == 64) {
+        // the fp32 buffers of the current parity receive a copy of the state (read-back, energies, scoring, the minimiser's exit test)
+        hipError_t e = c3d::launch_export64(dev_model(c), c->b64, c->parity, c->buf.X[c->parity], c->buf.V[c->parity], c->buf.P[c->parity], c->stream);
+        if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 export: ") + hipGetErrorString(e));
+        c->last_path = 3;
+    }
     return C3D_OK;
 }
 
@@ -597,6 +592,14 @@ int partials_finite(c3d_ctx* c, bool* ok) {
     return C3D_OK;
 }
 
+// fp64 state <- the fp32 coordinates of the current parity (start structures, c3d_set_coords, the DG embedding); velocities zero
+int import64(c3d_ctx* c) {
+    hipError_t e = c3d::launch_import64(dev_model(c), c->buf.X[c->parity], c->b64, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 import: ") + hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C3D_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -619,13 +622,15 @@ extern "C" void c3d_default_model(c3d_model* m) {
     //     (tools/calib/fit_structure.py, profiles/r03_structure_fit.txt): a plateau around the values below.
     m->min_sep = 5; m->noe_pot = 3; m->rep_sep = 2; m->ang_mode = 1;
     m->s_noe = 10.0f; m->rswitch = 0.5f; m->asym = 2.0f;   // tail slope = asym x rswitch x S = 10
-    m->k_bond = 400.0f; m->b0 = 3.93f;
-    m->k_ang = 43.0f; m->a0 = 5.9f;
-    m->r0_rep = 5.4f; m->k_rep = 3.85f;
+    m->k_bond = 500.0f; m->b0 = 3.93f;
+    m->k_ang = 15.0f; m->a0 = 5.55f;
+    m->r0_rep = 5.25f; m->k_rep = 4.0f;
     m->mass = 100.0f; m->fbeta = 10.0f;
-    // lower side of the NOE term: the force stops growing once a pair sits more than mrswitch inside its target
-    // (slope 2 mrswitch = no 1/D^2 term: the clamp form the fast kernels evaluate)
-    m->mrswitch = 4.0f; m->masym = 8.0f;
+    // lower side of the NOE term (round 4): square up to mrswitch inside the target, then the soft form with exponent 2 and no
+    // asymptote — the push on a pair far inside its target DECAYS as D^-3 beyond 10 A.  These are X-PLOR's own defaults for the soft
+    // potential (rswitch 10, asymptote 0, soexponent 2), which CNS keeps for the minus side because the deck's modules only set the
+    // plus side [CNS-UNVERIFIED]; the relaxation fit finds mrswitch = 9.9-10.0 on its own (profiles/r04_relax_fit.txt)
+    m->mrswitch = 10.0f; m->masym = 0.0f; m->msoexp = 2;
 }
 extern "C" void c3d_default_fire(c3d_fire_params* f) {
     if (!f) return;
@@ -728,7 +733,7 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
 
 extern "C" int c3d_set_model(c3d_ctx* c, const c3d_model* m) {
     if (!c || !m) return fail(C3D_ERR_INVALID, "c3d_set_model: null argument");
-    if (m->mass <= 0 || m->rswitch <= 0 || m->min_sep < 1 || m->rep_sep < 1 || m->rep_sep > 3 || m->noe_pot < 0 || m->noe_pot > 3 || m->mrswitch <= 0)
+    if (m->mass <= 0 || m->rswitch <= 0 || m->min_sep < 1 || m->rep_sep < 1 || m->rep_sep > 3 || m->noe_pot < 0 || m->noe_pot > 3 || m->mrswitch <= 0 || (m->msoexp != 1 && m->msoexp != 2))
         return fail(C3D_ERR_INVALID, "c3d_set_model: parameter out of range");
     if (c->have_targets && m->min_sep != c->model.min_sep)
         return fail(C3D_ERR_INVALID, "c3d_set_model: min_sep must be set before the targets are built");
@@ -1026,23 +1031,36 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
     c->pc = 0; c->parity = 0; c->steps_done = 0;
     if (c->precision == 64) {
         if (c->h_dist10.empty()) return fail(C3D_ERR_INVALID, "precision 64 needs targets built from an IF matrix (integer tenths)");
-        const size_t n3 = (size_t)nrep * n * 3;
-        if (!c->d64_X) {
-            HIP_TRY(hipMalloc(&c->d64_X, sizeof(double) * n3));
-            HIP_TRY(hipMalloc(&c->d64_V, sizeof(double) * n3));
-            HIP_TRY(hipMalloc(&c->d64_F, sizeof(double) * n3));
-            HIP_TRY(hipMalloc(&c->d64_Vinit, sizeof(double) * n3));
-            HIP_TRY(hipMalloc(&c->d64_L, sizeof(double) * 4 * nrep));
-            HIP_TRY(hipMalloc(&c->d64_fs, c3d::fire_state64_bytes() * nrep));
-            HIP_TRY(hipMalloc(&c->d64_t10, sizeof(int32_t) * (size_t)n * n));
-            HIP_TRY(hipMemcpyAsync(c->d64_t10, c->h_dist10.data(), sizeof(int32_t) * (size_t)n * n, hipMemcpyHostToDevice, c->stream));
+        if (n > c3d::kMaxBeads64) return fail(C3D_ERR_INVALID, "precision 64: more than 2560 beads are not supported by this build");
+        const int np = c3d::cols64(n);
+        const size_t n3 = (size_t)nrep * 3 * np, nP = (size_t)nrep * c->ntiles * 4;
+        if (!c->b64.T) {
+            DevTmp<int32_t> t10;
+            HIP_TRY(hipMalloc(&t10.p, sizeof(int32_t) * (size_t)n * n));
+            HIP_TRY(hipMemcpyAsync(t10.p, c->h_dist10.data(), sizeof(int32_t) * (size_t)n * n, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMalloc(&c->b64.T, sizeof(double) * (size_t)n * np));
+            hipError_t e = c3d::launch_targets64(dev_model(c), c->model.min_sep, t10.p, c->b64.T, c->stream);
+            if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 targets: ") + hipGetErrorString(e));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMalloc(&c->b64.Vinit, sizeof(double) * n3));
+            for (int k = 0; k < 2; ++k) {
+                HIP_TRY(hipMalloc(&c->b64.X[k], sizeof(double) * n3));
+                HIP_TRY(hipMalloc(&c->b64.V[k], sizeof(double) * n3));
+                HIP_TRY(hipMalloc(&c->b64.P[k], sizeof(double) * nP));
+                HIP_TRY(hipMalloc(&c->b64.S[k], c3d::fire_state64_bytes() * nrep));
+            }
         }
-        HIP_TRY(hipMemcpyAsync(c->d64_Vinit, v64.data(), sizeof(double) * n3, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d64_L, 0, sizeof(double) * 4 * nrep, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d64_fs, 0, c3d::fire_state64_bytes() * nrep, c->stream));
-        hipError_t e = c3d::launch_import64(dev_model(c), c->buf.X[0], c->d64_X, c->d64_V, c->stream);
-        if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 import: ") + hipGetErrorString(e));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<double> vs(n3, 0.0);       // Maxwell velocities in the SoA layout [nrep][3][np]
+        for (int r = 0; r < nrep; ++r)
+            for (int i = 0; i < n; ++i)
+                for (int k = 0; k < 3; ++k) vs[((size_t)r * 3 + k) * np + i] = v64[((size_t)r * n + i) * 3 + k];
+        HIP_TRY(hipMemcpyAsync(c->b64.Vinit, vs.data(), sizeof(double) * n3, hipMemcpyHostToDevice, c->stream));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipMemsetAsync(c->b64.P[k], 0, sizeof(double) * nP, c->stream));
+            HIP_TRY(hipMemsetAsync(c->b64.S[k], 0, c3d::fire_state64_bytes() * nrep, c->stream));
+        }
+        int rc = import64(c);
+        if (rc) return rc;
     }
     return C3D_OK;
 }
@@ -1075,6 +1093,7 @@ extern "C" int c3d_embed_replicas(c3d_ctx* c, int iters) {
                                         iters, v0.p, U.p, L.p, D2.p, c->buf.X[0], c->buf.X[1], c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("embed launch: ") + hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->precision == 64) return import64(c);
     return C3D_OK;
 }
 
@@ -1087,6 +1106,7 @@ extern "C" int c3d_set_coords(c3d_ctx* c, const float* xyz) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpyAsync(c->buf.X[c->parity], soa.data(), sizeof(float) * soa.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->precision == 64) return import64(c);
     return C3D_OK;
 }
 static int get_soa(c3d_ctx* c, const float* dev, float* aos) {
@@ -1244,7 +1264,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     const char* rs1 = (!general_tail(m) && m.rs == 1.0f) ? "true" : "false";
     if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %d, %s>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, m.wl, c->cl_plan.late_tiles ? "true" : "false");
     else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);
-    else if (c->precision == 64) snprintf(buf, sizeof(buf), "c3d::k64_force");
+    else if (c->precision == 64) snprintf(buf, sizeof(buf), "c3d::k64_step<%d, %s>", m.noe_pot, general_tail(m) ? "true" : "false");
     else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d, %s>", m.noe_pot, gen, m.rpw, (m.wl == 4 && m.nleft == 0) ? "false" : "true");
     return buf;
 }

@@ -524,7 +524,7 @@ hipError_t read_cluster_pstamps(unsigned long long* out) { return hipMemcpyFromS
 // Tile sums late (H0 fetches them after B1, LATE = true) where the pair loop of a compute wave — rows x column slots — outlasts
 // H0's later scalars; measured on 13 problems, N = 76 .. 455 (profiles/r03_late_tiles_ab.txt).  Shipped potential only: every
 // (geometry, LATE) pair is one more kernel to compile.
-constexpr bool cluster_late_ok(int pot, int rpw, int nb, int wl) { return pot == 3 && rpw * (4 * (nb - 1) + wl) >= 6; }
+constexpr bool cluster_late_ok(int pot, int rpw, int nb, int wl) { return pot >= 3 && rpw * (4 * (nb - 1) + wl) >= 6; }
 
 bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, int forced_late, ClusterPlan* plan) {
     // the placement arithmetic (replica r on XCD r % 8, XCC_ID & 7) is written for the 8 XCDs of an unpartitioned MI355X:
@@ -547,7 +547,7 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
         if (fcw && (cw != fcw || rpw != frpw || nh != fnh)) continue;
         if (rw % 8 || rw > 64) continue;
         if (rpw * nb > 8) continue;               // targets in registers: rpw * nb float4 per lane
-        if (m.noe_pot != 3 && (m.wl != 4 || m.nleft != 0)) continue;     // narrow last blocks and left-over columns: shipped potential only
+        if (m.noe_pot < 3 && (m.wl != 4 || m.nleft != 0)) continue;     // narrow last blocks and left-over columns: the CNS soft-square (3, 4) only
         if (m.nleft > 0 && (nh != 4 || (rw + 8 * (nh - 1) - 1) / (8 * (nh - 1)) > 4)) continue;       // left-over passes per chain helper (three of them)
         const int P = (m.n + rw - 1) / rw;
         if (per_xcd * P > cus_per_xcd * wpc) continue;
@@ -616,7 +616,7 @@ static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const Clust
 #define C3D_CL(R, B)                                                                                                    \
     if (pl.rpw == R && m.npad == 256 * B) {                                                                             \
         if (m.wl == 4) C3D_GO(R, B, 4);                                                                                 \
-        if constexpr (POT == 3) {   /* narrower last blocks: the shipped potential only (cluster_plan refuses the others) */      \
+        if constexpr (POT >= 3) {   /* narrower last blocks: the CNS soft-square only (cluster_plan refuses the others)    */      \
             if (m.wl == 3) C3D_GO(R, B, 3);                                                                             \
             if (m.wl == 2) C3D_GO(R, B, 2);                                                                             \
             if (m.wl == 1) C3D_GO(R, B, 1);                                                                             \
@@ -639,6 +639,7 @@ hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPla
         case 0: return cluster_geom<0>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
         case 1: return cluster_geom<1>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
         case 3: return cluster_geom<3>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
+        case 4: return cluster_geom<4>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
         default: return cluster_geom<2>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
     }
 }

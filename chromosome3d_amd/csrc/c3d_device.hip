@@ -189,6 +189,7 @@ hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, c
             case 0: return launch_step_t<0, false>(m, p, fp, b, parity, s);
             case 1: return launch_step_t<1, false>(m, p, fp, b, parity, s);
             case 3: return launch_step_t<3, false>(m, p, fp, b, parity, s);
+            case 4: return launch_step_t<4, false>(m, p, fp, b, parity, s);
             default: return launch_step_t<2, false>(m, p, fp, b, parity, s);
         }
     }
@@ -196,6 +197,7 @@ hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, c
         case 0: return launch_step_t<0, true>(m, p, fp, b, parity, s);
         case 1: return launch_step_t<1, true>(m, p, fp, b, parity, s);
         case 3: return launch_step_t<3, true>(m, p, fp, b, parity, s);
+        case 4: return launch_step_t<4, true>(m, p, fp, b, parity, s);
         default: return launch_step_t<2, true>(m, p, fp, b, parity, s);
     }
 }
@@ -234,9 +236,9 @@ hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuff
     const dim3 g = grid_blocks(m), blk(kEvalBlock);
 #define C3D_EVAL(POT, GEN) hipLaunchKernelGGL((k_eval_forces<POT, GEN>), g, blk, lds, s, m, p, b.tgt, b.X[parity], Fout)
     if (!general_tail) {
-        if (m.noe_pot == 0) C3D_EVAL(0, false); else if (m.noe_pot == 1) C3D_EVAL(1, false); else if (m.noe_pot == 3) C3D_EVAL(3, false); else C3D_EVAL(2, false);
+        if (m.noe_pot == 0) C3D_EVAL(0, false); else if (m.noe_pot == 1) C3D_EVAL(1, false); else if (m.noe_pot == 3) C3D_EVAL(3, false); else if (m.noe_pot == 4) C3D_EVAL(4, false); else C3D_EVAL(2, false);
     } else {
-        if (m.noe_pot == 0) C3D_EVAL(0, true); else if (m.noe_pot == 1) C3D_EVAL(1, true); else if (m.noe_pot == 3) C3D_EVAL(3, true); else C3D_EVAL(2, true);
+        if (m.noe_pot == 0) C3D_EVAL(0, true); else if (m.noe_pot == 1) C3D_EVAL(1, true); else if (m.noe_pot == 3) C3D_EVAL(3, true); else if (m.noe_pot == 4) C3D_EVAL(4, true); else C3D_EVAL(2, true);
     }
 #undef C3D_EVAL
     return hipGetLastError();
@@ -257,7 +259,10 @@ __global__ __launch_bounds__(256) void k_energy(const DevModel m, const float s_
     double e_noe = 0, e_bond = 0, e_rep = 0;
     const double rs = m.rs, c = m.tail_c, b = m.tail_b;
     const double a = rs * rs - b / rs - c * rs;
-    const double mrs = m.mrs, mc = m.mtail_c, mb = m.mtail_b, ma = mrs * mrs - mb / mrs - mc * mrs;   // noe_pot 3: lower side
+    // noe_pot 3 / 4, lower side: E = ma + mb / D^mexp + mc D beyond mrs (DevModel::mtail_b is the force's coefficient: mb x mexp)
+    const bool pot3 = m.noe_pot == 3 || m.noe_pot == 4;
+    const double mrs = m.mrs, mc = m.mtail_c, mb = m.mexp == 2 ? 0.5 * m.mtail_b : m.mtail_b;
+    const double ma = mrs * mrs - (m.mexp == 2 ? mb / (mrs * mrs) : mb / mrs) - mc * mrs;
     for (int i = tid; i < m.n; i += 256) {
         const double xi = x[i], yi = y[i], zi = z[i];
         for (int j = i + 1; j < m.n; ++j) {
@@ -270,8 +275,8 @@ __global__ __launch_bounds__(256) void k_energy(const DevModel m, const float s_
             if (t > 0) {
                 const double delta = sqrt(r2) - t, ad = fabs(delta);
                 bool soft;
-                if (m.noe_pot == 0) soft = ad > rs; else if (m.noe_pot == 1 || m.noe_pot == 3) soft = delta > rs; else soft = false;
-                if (m.noe_pot == 3 && delta < -mrs) e_noe += ma + mb / ad + mc * ad;
+                if (m.noe_pot == 0) soft = ad > rs; else if (m.noe_pot == 1 || pot3) soft = delta > rs; else soft = false;
+                if (pot3 && delta < -mrs) e_noe += ma + (m.mexp == 2 ? mb / (ad * ad) : mb / ad) + mc * ad;
                 else e_noe += soft ? (a + b / ad + c * ad) : delta * delta;
             }
             if (sep == 1) { const double dl = sqrt(r2) - m.b0; e_bond += 0.5 * m.k_bond2 * dl * dl; }

@@ -23,9 +23,10 @@ struct DevModel {
     int rep_base, nrep_g;          // replica group of this launch: [rep_base, rep_base + nrep_g)
     int stage_dma;                 // 1: coordinates staged with global_load_lds (async), 0: through registers
     int rpw;                       // rows per wave of the step kernel (1, 2 or 4); waves/WG = kTileRows/rpw
-    int noe_pot, ang_mode, rep_sep;
+    int noe_pot, ang_mode, rep_sep; // noe_pot: the c3d_model's 0..3, or 4 = 3 with the lower side's fast soft form (msoexp 2, masym 0)
+    int mexp;                      // noe_pot 3 / 4, lower side: exponent of the soft form (c3d_model::msoexp, 1 or 2)
     float rs, tail_c, tail_b;      // soft tail: dE/dD = tail_c - tail_b / D^2  (D > rs)
-    float mrs, mtail_c, mtail_b;   // noe_pot 3, lower side: dE/dD = mtail_c - mtail_b / D^2  (D = t - d > mrs)
+    float mrs, mtail_c, mtail_b;   // noe_pot 3, lower side: dE/dD = mtail_c - mtail_b / D^(mexp + 1)  (D = t - d > mrs)
     float nmrs;                    // -mrs
     float inv_rs, nm_rs;           // 1 / rs, -mrs / rs: the clamp form works on (d - t) / (rs d), see pair_term
     // Column layout of the pair loop (c3d_step_core.h): blocks of 256 columns, lane l owns 4 consecutive ones — except in the LAST
@@ -129,14 +130,27 @@ size_t sym_scratch_floats(const DevModel& m);
 void sym_tile_list(const DevModel& m, int2* out);
 hipError_t launch_step_sym(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int parity, const void* tiles,
                            float* scratch, hipStream_t s);
-// fp64 step (c3d_f64.hip, option "precision" = 64): the CPU restatement's algorithm in its precision on the GPU.
-// model_host[14] = s_noe, rswitch, asym, masym, mrswitch, k_bond, b0, k_ang, a0, r0_rep, k_rep, mass, fbeta, min_sep;
+// fp64 step (c3d_f64.hip, option "precision" = 64): the CPU restatement's algorithm in its precision on the GPU, one launch per SA
+// step of a replica group (k64_step), double buffered by step parity like the fp32 per-step path.
+// model_host[15] = s_noe, rswitch, asym, masym, mrswitch, k_bond, b0, k_ang, a0, r0_rep, k_rep, mass, fbeta, min_sep, msoexp;
 // step_host[6] = kind, dt, w_all, w_vdw, repel_s, t_bath; fire_host[7] = dt_start, dt_max, f_inc, f_dec, alpha_start, f_alpha, max_step.
-// X, V, F, Vinit: [nrep][n][3] doubles; L: [nrep][4]; fs: nrep * fire_state64_bytes(); t10: n*n tenths of an Angstrom.
+// Layouts (np = cols64(n): n rounded up to 128): T [n][np] targets in Angstrom (0.1 * t10, 0 = none); X, V [2][nrep][3][np] SoA;
+// Vinit [nrep][3][np]; P [2][nrep][ntiles][4] per-tile sums; S [2][nrep] x fire_state64_bytes().
+struct Buffers64 {
+    double* T = nullptr;
+    double* X[2] = {nullptr, nullptr};
+    double* V[2] = {nullptr, nullptr};
+    double* Vinit = nullptr;
+    double* P[2] = {nullptr, nullptr};
+    void* S[2] = {nullptr, nullptr};
+};
+int cols64(int n);
+constexpr int kMaxBeads64 = 2560;     // 3 * 8 * np bytes of LDS must stay below the 64 KB a launch gets without opt-in
 hipError_t launch_step64(const DevModel& d, const double* model_host, const double* step_host, const double* fire_host, int fire_n_min,
-                         const int32_t* t10, double* X, double* V, double* F, const double* Vinit, double* L, void* fs, hipStream_t s);
-hipError_t launch_import64(const DevModel& d, const float* Xf, double* X, double* V, hipStream_t s);
-hipError_t launch_export64(const DevModel& d, const double* X, const double* V, const double* L, float* Xf, float* Vf, float* Pf, hipStream_t s);
+                         const Buffers64& b, int parity, hipStream_t s);
+hipError_t launch_targets64(const DevModel& d, int min_sep, const int32_t* t10, double* T, hipStream_t s);
+hipError_t launch_import64(const DevModel& d, const float* Xf, const Buffers64& b, hipStream_t s);
+hipError_t launch_export64(const DevModel& d, const Buffers64& b, int parity, float* Xf, float* Vf, float* Pf, hipStream_t s);
 size_t fire_state64_bytes();
 // K1: IF (n*n fp64, device) -> dist10 (n*n int32, device) and encoded targets (n*npad, device)
 hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, double K, int min_sep, int rep_sep,

@@ -84,6 +84,7 @@ __device__ __forceinline__ float noe_grad(float delta, const DevModel& m) {
     if constexpr (!GEN) {  // tail slope == 2*rs (and 2*mrs on the lower side of POT 3), b == 0
         if constexpr (POT == 1) return 2.0f * fminf(delta, m.rs);
         else if constexpr (POT == 0) return 2.0f * fminf(fmaxf(delta, -m.rs), m.rs);
+        else if constexpr (POT == 4) { const float D = fmaxf(-delta, m.mrs); const float q = m.mrs / D; return 2.0f * fminf(fmaxf(delta, -m.mrs * q * q * q), m.rs); }
         else if constexpr (POT == 3) return 2.0f * fminf(fmaxf(delta, -m.mrs), m.rs);
         else return 2.0f * delta;
     } else {
@@ -91,7 +92,10 @@ __device__ __forceinline__ float noe_grad(float delta, const DevModel& m) {
         const float tail = m.tail_c - m.tail_b / (ad * ad);
         if constexpr (POT == 1) return delta > m.rs ? tail : 2.0f * delta;
         else if constexpr (POT == 0) return ad > m.rs ? copysignf(tail, delta) : 2.0f * delta;
-        else if constexpr (POT == 3) return delta > m.rs ? tail : (delta < -m.mrs ? m.mtail_b / (ad * ad) - m.mtail_c : 2.0f * delta);
+        else if constexpr (POT == 3 || POT == 4) {          // lower side: mtail_c - mtail_b / D^(mexp + 1)
+            const float dp = m.mexp == 2 ? ad * ad * ad : ad * ad;
+            return delta > m.rs ? tail : (delta < -m.mrs ? m.mtail_b / dp - m.mtail_c : 2.0f * delta);
+        }
         else return 2.0f * delta;
     }
 }
@@ -180,6 +184,18 @@ __device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, c
         if constexpr (POT == 1) s = fminf(u, rinv);
         else if constexpr (POT == 0) s = __builtin_amdgcn_fmed3f(u, -rinv, rinv);
         else if constexpr (POT == 3) s = __builtin_amdgcn_fmed3f(u, k.nm_rs * rinv, rinv);   // clamp(u, -mrs/(rs d), 1/d): one v_med3_f32
+        else if constexpr (POT == 4) {
+            // lower side square up to D = t - d = mrs, then the CNS soft form with exponent 2 and no asymptote: dE/dD = 2 mrs^4 / D^3.
+            // In the clamp form's variable (D = -rs u d) that is s = -(mrs / rs)^4 rinv^4 / |u|^3: the lower BOUND of the same v_med3 —
+            // it lies below u while D < mrs and above it beyond; above the target it is negative and never binds.  u = 0 (no restraint,
+            // or d = t): rcp = inf, the bound -inf, s = u = 0.  With kr = -(mrs / rs) rinv (POT 3's bound) and z = kr / |u| the bound is
+            // ((kr z) z) |z|: v_rcp_f32 and four multiplications more than POT 3, none of them of the src0 = src1 kind.  (Forming
+            // it only in waves that hold a pair that deep — a compare and a scalar branch per pair term — was measured slower:
+            // 4.70 against 4.46 us per step at chr1_500kb x 20, profiles/r04_lower_side_forms.txt.)
+            const float kr = k.nm_rs * rinv;
+            const float z = kr * __builtin_amdgcn_rcpf(fabsf(u));
+            s = __builtin_amdgcn_fmed3f(u, ((kr * z) * z) * fabsf(z), rinv);
+        }
         else s = u;
         c = fmaf(k.kq, q01, s);
     } else {

@@ -83,6 +83,10 @@ __global__ __launch_bounds__(256) void k_pairs_sym(const float* __restrict__ xin
                 if constexpr (POT == 1) s = fminf(u, lim);
                 else if constexpr (POT == 0) s = fminf(fmaxf(u, -lim), lim);
                 else if constexpr (POT == 3) s = __builtin_amdgcn_fmed3f(u, m.nmrs * rinv, lim);
+                else if constexpr (POT == 4) {      // lower side soft beyond mrs (c3d_step_core.h pair_term, in this kernel's variable u = (d - t) / d)
+                    const float kr = m.nmrs * rinv, z = kr * __builtin_amdgcn_rcpf(fabsf(u));
+                    s = __builtin_amdgcn_fmed3f(u, ((kr * z) * z) * fabsf(z), lim);
+                }
                 else s = u;
                 float c = ww[k] * s;
                 float q01;
@@ -240,6 +244,7 @@ hipError_t launch_step_sym(const DevModel& m, const DevStep& p, const DevFire& f
         case 0: C3D_SYM(0);
         case 1: C3D_SYM(1);
         case 3: C3D_SYM(3);
+        case 4: C3D_SYM(4);
         default: C3D_SYM(2);
     }
 #undef C3D_SYM

@@ -22,7 +22,8 @@ class Model(C.Structure):
     _fields_ = [("min_sep", C.c_int32), ("noe_pot", C.c_int32), ("rep_sep", C.c_int32), ("ang_mode", C.c_int32),
                 ("s_noe", C.c_float), ("rswitch", C.c_float), ("asym", C.c_float),
                 ("k_bond", C.c_float), ("b0", C.c_float), ("k_ang", C.c_float), ("a0", C.c_float),
-                ("r0_rep", C.c_float), ("k_rep", C.c_float), ("mass", C.c_float), ("fbeta", C.c_float), ("masym", C.c_float), ("mrswitch", C.c_float)]
+                ("r0_rep", C.c_float), ("k_rep", C.c_float), ("mass", C.c_float), ("fbeta", C.c_float), ("masym", C.c_float), ("mrswitch", C.c_float),
+                ("msoexp", C.c_int32)]
 
 
 class Stage(C.Structure):

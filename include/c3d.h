@@ -43,13 +43,13 @@ typedef struct c3d_ctx c3d_ctx;
  * con_wt chromosome3D.pl:66,1111,1120; mass/fbeta :1415-1416; SEPARATION :20. */
 typedef struct {
     int32_t min_sep;   /* 5: restraints only for |i-j| >= min_sep                        */
-    int32_t noe_pot;   /* 0 symmetric soft-square, 1 X-PLOR soft-square (default), 2 square,
-                          3 CNS soft-square with a soft LOWER side too (slope masym beyond mrswitch) */
+    int32_t noe_pot;   /* 0 symmetric soft-square, 1 X-PLOR soft-square, 2 square,
+                          3 CNS soft-square with a soft LOWER side too (mrswitch, masym, msoexp; default) */
     int32_t rep_sep;   /* repel acts on |i-j| >= rep_sep (1..3)                          */
     int32_t ang_mode;  /* (i,i+2) term: 0 lower bound only, 1 harmonic                   */
     float s_noe;       /* NOE scale = con_wt = 10                                        */
-    float rswitch;     /* 1.0                                                            */
-    float asym;        /* 2.0 asymptote slope                                            */
+    float rswitch;     /* 0.5: the upper side is square up to d - t = rswitch            */
+    float asym;        /* 2.0: slope of the upper tail in units of rswitch (tail slope = asym x rswitch x S = 10) */
     float k_bond, b0;  /* pseudo-bond (i,i+1)                                            */
     float k_ang, a0;   /* pseudo-angle (i,i+2)                                           */
     float r0_rep;      /* bead contact distance, scaled by stage `repel`                 */
@@ -58,6 +58,10 @@ typedef struct {
     float fbeta;       /* 10 /ps                                                         */
     float masym;       /* noe_pot 3: asymptote slope of the lower side (CNS masymptote)  */
     float mrswitch;    /* noe_pot 3: the lower side is square up to t - d = mrswitch     */
+    int32_t msoexp;    /* noe_pot 3: exponent of the lower side's soft form a + b / D^msoexp + masym D beyond mrswitch
+                          (CNS msoexponent), 1 or 2.  Shipped: mrswitch 10, masym 0, msoexp 2 — X-PLOR's own defaults
+                          (rswitch 10, asymptote 0, soexponent 2), which the deck never overrides for the minus side:
+                          the push on a pair far inside its target rises to 2 S mrswitch and then DECAYS as D^-3     */
 } c3d_model;
 
 /* One stage of the annealing schedule (defaults: c3d_default_schedule, which restates

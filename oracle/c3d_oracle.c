@@ -246,6 +246,7 @@ typedef struct {
     double a0;        /* (i,i+2) lower bound distance */
     double mass;      /* 100  chromosome3D.pl:1416 */
     double fbeta;     /* 10   chromosome3D.pl:1415 */
+    int msoexp;       /* noe_pot 3: exponent of the lower side's soft form, 1 or 2 (CNS msoexponent) [CNS-UNVERIFIED] */
 } c3o_model;
 
 typedef struct {
@@ -275,9 +276,15 @@ static inline double softsq(const c3o_model* m, double delta, double* e) {
     else if (m->noe_pot == 1) soft = delta > rs;
     else if (m->noe_pot == 3) {
         const double mrs = m->mrswitch;
-        if (delta < -mrs) {  /* lower side: CNS minus-side soft form a + b/D + c D, c = masym
-                                (msoexponent 1), C1-continuous at D = mrswitch */
+        if (delta < -mrs) {  /* lower side: CNS minus-side soft form a + b/D^p + c D, c = masym, p = msoexponent
+                                (1 or 2), C1-continuous at D = mrswitch */
             const double mc = m->masym;
+            if (m->msoexp == 2) {
+                const double mb = (mc - 2.0 * mrs) * mrs * mrs * mrs / 2.0;      /* from c - 2 b / mrs^3 = 2 mrs */
+                const double ma = mrs * mrs - mb / (mrs * mrs) - mc * mrs;
+                *e += ma + mb / (ad * ad) + mc * ad;
+                return -(-2.0 * mb / (ad * ad * ad) + mc);
+            }
             const double mb = (mc - 2.0 * mrs) * mrs * mrs;
             const double ma = mrs * mrs - mb / mrs - mc * mrs;
             *e += ma + mb / ad + mc * ad;

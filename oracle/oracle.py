@@ -25,7 +25,7 @@ class Model(C.Structure):
                 ("s_noe", C.c_double), ("rswitch", C.c_double), ("asym", C.c_double), ("masym", C.c_double), ("mrswitch", C.c_double),
                 ("k_bond", C.c_double), ("b0", C.c_double), ("r0_rep", C.c_double),
                 ("k_rep", C.c_double), ("k_ang", C.c_double), ("a0", C.c_double),
-                ("mass", C.c_double), ("fbeta", C.c_double)]
+                ("mass", C.c_double), ("fbeta", C.c_double), ("msoexp", C.c_int)]
 
 
 class Stage(C.Structure):
@@ -145,7 +145,7 @@ def write_front_half(outdir, cid, dist10, rr):
 
 def default_model(n, **kw):
     m = Model(n=n, min_sep=5, noe_pot=0, rep_sep=2, ang_mode=0, s_noe=10.0, rswitch=1.0, asym=2.0, masym=0.1, mrswitch=1.0,
-              k_bond=100.0, b0=3.8, r0_rep=4.0, k_rep=1.0, k_ang=0.0, a0=5.0, mass=100.0, fbeta=10.0)
+              k_bond=100.0, b0=3.8, r0_rep=4.0, k_rep=1.0, k_ang=0.0, a0=5.0, mass=100.0, fbeta=10.0, msoexp=1)
     for k, v in kw.items():
         setattr(m, k, v)
     return m

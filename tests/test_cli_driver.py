@@ -140,6 +140,38 @@ def test_batch_script_runs_every_matrix(built, tmp_path):
         assert len(list((tmp_path / "out" / cid).glob(f"{cid}_matrix_model*.pdb"))) == 5
 
 
+def test_perl_driver_seq_option_cannot_reach_a_shell(built, tmp_path):
+    """-seq <fasta> names residues (reference :93-98).  A hostile FASTA (stop codon '*', ';', '$( )', backticks) is refused before
+    anything runs; a clean one travels to c3d_solve as `--seq '@<ID>.fasta'` — the file the driver wrote — and every string on the
+    job.sh line is single-quoted.  No GPU needed: the solver is a stand-in script that records its arguments."""
+    if shutil.which("perl") is None:
+        pytest.skip("no perl here")
+    drv = os.path.join(ROOT, "bin", "chromosome3D_amd.pl")
+    canary = tmp_path / "canary"
+    for k, text in enumerate((">x\nMKV*\n", ">x\nMKV;touch " + str(canary) + "\n", ">x\nM$(touch " + str(canary) + ")K\n", ">x\nM`touch " + str(canary) + "`K\n")):
+        fa = tmp_path / f"bad{k}.fasta"
+        fa.write_text(text)
+        out = subprocess.run(["perl", drv, "-i", MATRIX, "-o", str(tmp_path / f"bad{k}"), "-m", "2", "-seq", str(fa)],
+                             capture_output=True, text=True, env=dict(os.environ, C3D_FORCE_CLI="1"))
+        assert out.returncode != 0 and "residue codes must be letters" in out.stderr, out.stderr
+        assert not canary.exists() and not (tmp_path / f"bad{k}" / "job.sh").exists()
+    fake = tmp_path / "fake_solve.sh"
+    fake.write_text("#!/bin/bash\nprintf '%s\\n' \"$@\" > args.txt\nexit 3\n")
+    fake.chmod(0o755)
+    fa = tmp_path / "ok.fasta"
+    fa.write_text(">x\nrsedw\nQC\n")
+    od = tmp_path / "ok"
+    out = subprocess.run(["perl", drv, "-i", MATRIX, "-o", str(od), "-m", "2", "-seq", str(fa)], capture_output=True, text=True,
+                         env=dict(os.environ, C3D_FORCE_CLI="1", C3D_SOLVE=str(fake)))
+    assert out.returncode != 0                                      # the stand-in writes no models: the driver must say so
+    cid = "chr21_1mb_matrix"
+    assert open(od / f"{cid}.fasta").read() == f">{cid}\nRSEDWQC" + "M" * 30 + "\n"
+    args = open(od / "args.txt").read().split("\n")
+    assert args[args.index("--seq") + 1] == f"@{cid}.fasta" and args[args.index("--id") + 1] == cid
+    line = [l for l in open(od / "job.sh") if "--seq" in l][0]
+    assert f"--seq '@{cid}.fasta'" in line and f"--id '{cid}'" in line and "RSEDWQC" not in line
+
+
 def test_perl_driver_fails_loudly_without_gpu(built, tmp_path):
     """Error convention of the reference (:281-288): iam.failed + die, through both binding routes."""
     from chromosome3d_amd import lib

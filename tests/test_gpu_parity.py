@@ -107,8 +107,9 @@ def _force_close(F, Fo):
 @pytest.mark.parametrize("pot", [0, 1, 2, 3])
 def test_force_energy_parity(solver, O, cid, pot):
     """All four NOE potentials; pot 3 is the shipped default.  The collapsed coils (x 0.4, x 0.15) put thousands of pairs
-    more than mrswitch (4 A) INSIDE their targets, the stretched one (x 1.0) thousands beyond rswitch: both clamps of
-    pot 3 are exercised, at the default switch distances and at rswitch = 1 (the other compile-time variant)."""
+    more than mrswitch INSIDE their targets (beyond 4 A and beyond 10 A), the stretched one (x 1.0) thousands beyond rswitch:
+    both sides of pot 3 are exercised — in the shipped form (lower side soft beyond 10 A with exponent 2: the fast device
+    potential 4), in round 3's clamp form (mrswitch 4, slope 8) and at rswitch = 1 (the other compile-time variant)."""
     from chromosome3d_amd import default_model, pipeline
     IF = load_if(cid)
     n = IF.shape[0]
@@ -121,7 +122,9 @@ def test_force_energy_parity(solver, O, cid, pot):
         ok = t[i, j] > 0
         d = np.linalg.norm(x[1][i] - x[1][j], axis=1)[ok]
         assert (d - t[i, j][ok] < -4.0).sum() > 20 and (np.linalg.norm(x[0][i] - x[0][j], axis=1)[ok] - t[i, j][ok] > 0.5).sum() > 20
-    for extra in (({}, dict(rswitch=1.0, mrswitch=11.0, masym=22.0)) if pot == 3 else ({},)):
+        assert (np.linalg.norm(x[2][i] - x[2][j], axis=1)[ok] - t[i, j][ok] < -10.0).sum() > 20
+        assert default_model().msoexp == 2 and default_model().masym == 0.0
+    for extra in (({}, dict(mrswitch=4.0, masym=8.0, msoexp=1), dict(rswitch=1.0, mrswitch=11.0, masym=22.0)) if pot == 3 else ({},)):
         m = default_model(noe_pot=pot, **extra)
         _force_energy_case(solver, O, m, d10, x, n, nrep, cid, pot)
 
@@ -147,8 +150,10 @@ def test_force_parity_general_tail_and_lower_bound_angle(solver, O):
     n = IF.shape[0]
     d10 = pipeline.IF2dist_new(solver, IF)
     for kw in (dict(noe_pot=1, asym=1.0, rswitch=0.5), dict(noe_pot=0, asym=3.0, rswitch=2.0),
-               dict(noe_pot=3, mrswitch=4.0, masym=3.0), dict(noe_pot=3, mrswitch=6.0, masym=0.0, asym=1.5, rswitch=1.0),
-               dict(noe_pot=3, mrswitch=2.0, masym=9.0),
+               dict(noe_pot=3, mrswitch=4.0, masym=3.0, msoexp=1), dict(noe_pot=3, mrswitch=6.0, masym=0.0, asym=1.5, rswitch=1.0, msoexp=1),
+               dict(noe_pot=3, mrswitch=2.0, masym=9.0, msoexp=1),
+               dict(noe_pot=3, mrswitch=6.0, masym=1.5, msoexp=2), dict(noe_pot=3, mrswitch=8.0, masym=0.0, msoexp=1),
+               dict(noe_pot=3, mrswitch=5.0, masym=0.0, msoexp=2, asym=1.2),
                dict(noe_pot=1, ang_mode=0, k_ang=200.0, a0=6.0), dict(noe_pot=1, k_ang=0.0)):
         m = default_model(**kw)
         solver.set_model(m)
@@ -362,7 +367,7 @@ def test_fp64_path_follows_the_oracle_over_long_trajectories(solver, O, cid, nst
         IF, d10, m, fire = _setup(solver, cid, stages)
         x0 = solver.coords()
         assert solver.run_steps(10 ** 6) == a + b + c + d
-        assert solver.step_kernel_name == "c3d::k64_force"
+        assert solver.step_kernel_name.startswith("c3d::k64_step<")
         x, v = solver.coords(), solver.velocities()
         om, of = oracle_model_from(m, IF.shape[0]), oracle_fire_from(fire)
         for r in range(2):

@@ -54,7 +54,7 @@ def oracle_model_from(m, n):
     return O.default_model(n, min_sep=m.min_sep, noe_pot=m.noe_pot, rep_sep=m.rep_sep, ang_mode=m.ang_mode,
                            s_noe=float(m.s_noe), rswitch=float(m.rswitch), asym=float(m.asym), masym=float(m.masym), mrswitch=float(m.mrswitch),
                            k_bond=float(m.k_bond), b0=float(m.b0), k_ang=float(m.k_ang), a0=float(m.a0),
-                           r0_rep=float(m.r0_rep), k_rep=float(m.k_rep), mass=float(m.mass), fbeta=float(m.fbeta))
+                           r0_rep=float(m.r0_rep), k_rep=float(m.k_rep), mass=float(m.mass), fbeta=float(m.fbeta), msoexp=int(m.msoexp))
 
 
 def oracle_fire_from(f):

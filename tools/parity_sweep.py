@@ -8,7 +8,7 @@ solver evidence the reference holds): per matrix
   * the chain envelope: bond mean/sd, |i-j| = 2 mean/sd, radius of gyration ratio.
 
     python tools/parity_sweep.py ['{json model overrides}'] [replicas=20] [subset regex]
-Extra keys in the overrides: min_steps, quiet, embed, seed, dump (path of an .npz receiving every replica's coordinates).
+Extra keys in the overrides: min_steps, quiet, embed (DG-embed start, chromosome3D.pl:1471-1525), start (1 = extended strand, :2413-2416), seed, dump (path of an .npz receiving every replica's coordinates).
 Prints a markdown table; the committed copy lives in profiles/.
 """
 import glob, json, os, re, sys, time
@@ -35,7 +35,8 @@ def all_cids():
     return sorted({os.path.basename(p)[:-len("_upper.npz")] for p in glob.glob(f"{ALL}/*_upper.npz") if "standin" not in np.load(p).files}, key=key)
 
 
-def solve(s, IF, over, nrep=20, seed=82364, min_steps=3000, embed=0):
+def solve(s, IF, over, nrep=20, seed=82364, min_steps=3000, embed=0, start=0):
+    s.set_option("start", start)
     s.set_model(default_model(**over))
     d10 = pipeline.IF2dist_new(s, IF)
     s.set_schedule(default_schedule(min_steps), default_fire(), 0.0, 250)
@@ -84,7 +85,7 @@ def main():
     nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     subset = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
     min_steps = int(over.pop("min_steps", 3000)); quiet = over.pop("quiet", 0); embed = over.pop("embed", 0)
-    seed = int(over.pop("seed", 82364)); dump = over.pop("dump", None)
+    seed = int(over.pop("seed", 82364)); dump = over.pop("dump", None); start = int(over.pop("start", 0))
     s = Solver(0)
     reps, t_all, store = [], time.time(), {}
     if not quiet:
@@ -99,7 +100,7 @@ def main():
         Xr = load_pdb_xyz(ref[0])
         if len(Xr) != IF.shape[0]:
             continue
-        x, e, rows = solve(s, IF, over, nrep, seed, min_steps, embed)
+        x, e, rows = solve(s, IF, over, nrep, seed, min_steps, embed, start)
         ms = s.last_timing()[0]
         rank = bundled_rank(ref[0])
         rep = structure_report(IF, x, e[:, 0], Xr, rank, rows)
@@ -109,7 +110,7 @@ def main():
             store[cid] = x; store[cid + "_e"] = e
         if not quiet:
             print(row(cid, IF.shape[0], s.num_restraints, rep, rank, ms), flush=True)
-    print(summary(reps) + f"; overrides {over}; seed {seed}; total {time.time() - t_all:.1f} s", flush=True)
+    print(summary(reps) + f"; overrides {over}; start {'DG embed' if embed else ('extended strand' if start else 'random coil')}; seed {seed}; total {time.time() - t_all:.1f} s", flush=True)
     if dump:
         np.savez_compressed(dump, **store)
 
