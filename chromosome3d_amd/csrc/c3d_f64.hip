@@ -91,12 +91,14 @@ __device__ __forceinline__ double reduce_rows64(double a0, double a1, int lane) 
 // d = sqrt(r2) and h = 1 / (2 d) together: v_rsq_f64 (2^29 ulp: 23 bits) + two coupled Newton steps (Goldschmidt form);
 // the results are within an ulp or two of the correctly rounded values (r2 >= 1e-12: no denormal, no zero)
 __device__ __forceinline__ void sqrt_hrsqrt64(double r2, double& d, double& h) {
-    const double y = __builtin_amdgcn_rsq(r2);
+    const double y = (double)__builtin_amdgcn_rsqf((float)r2);      // 23-bit seed from the fp32 unit (v_rsq_f64 is no better and slower); 1e-12 <= r2 <= 1e9
     double g = r2 * y;
     h = 0.5 * y;
     double r = fma(-g, h, 0.5);
+#ifdef C3D_F64_TWO_NEWTON
     g = fma(g, r, g); h = fma(h, r, h);
     r = fma(-g, h, 0.5);
+#endif
     d = fma(g, r, g); h = fma(h, r, h);
 }
 
@@ -111,11 +113,13 @@ __device__ __forceinline__ double half_noe_grad64(const Model64& m, double delta
             // lower side beyond mrs: dE/dD = 2 mrs^4 / D^3 (soft form, exponent 2, no asymptote) = the lower bound -mrs (mrs / D)^3 of
             // the same clamp; 1 / D from v_rcp_f64 and two Newton steps, D held at >= mrs (the bound is -mrs inside the square part)
             const double D = fmax(-delta, m.mrs);
-            double y = __builtin_amdgcn_rcp(D);
+            double y = (double)__builtin_amdgcn_rcpf((float)D);
             double e = fma(-D, y, 1.0);
             y = fma(y, e, y);
+#ifdef C3D_F64_TWO_NEWTON
             e = fma(-D, y, 1.0);
             y = fma(y, e, y);
+#endif
             const double q = m.mrs * y;
             return fmin(fmax(delta, -m.mrs * (q * q * q)), m.rs);
         }
@@ -167,7 +171,7 @@ __device__ __forceinline__ void chain64(const Model64& m, const Step64& p, doubl
 
 // P: [nrep][ntiles][4] per-tile sums of the previous step — MD kinds: (sum v^2, sum vx, vy, vz); FIRE: (v.F, F.F, v.v, 0)
 template <int POT, bool GEN>
-__global__ __launch_bounds__(kBlock64) void k64_step(const Model64 m, const Step64 p, const Fire64 fp, const int rep_base,
+__global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) void k64_step(const Model64 m, const Step64 p, const Fire64 fp, const int rep_base,
                                                     const double* __restrict__ T, const double* __restrict__ xin,
                                                     const double* __restrict__ vin, const double* __restrict__ vinit,
                                                     const double* __restrict__ pin, const FireState64* __restrict__ sin,

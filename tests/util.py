@@ -108,12 +108,13 @@ def bundled_rank(path):
 
 
 def chain_stats(x):
-    """(bond mean, bond sd, |i-j|=2 mean, |i-j|=2 sd, radius of gyration) of one model [N, 3] — the envelope SURVEY 8a/8c names."""
+    """(bond mean, bond sd, |i-j|=2 mean, |i-j|=2 sd, radius of gyration, |i-j|=2 5 % and 95 % quantiles) of one model [N, 3] — the
+    envelope SURVEY 8a/8c names."""
     x = np.asarray(x, dtype=np.float64)
     b = np.linalg.norm(x[1:] - x[:-1], axis=1)
     a = np.linalg.norm(x[2:] - x[:-2], axis=1)
     rg = float(np.sqrt(((x - x.mean(0)) ** 2).sum(1).mean()))
-    return float(b.mean()), float(b.std()), float(a.mean()), float(a.std()), rg
+    return float(b.mean()), float(b.std()), float(a.mean()), float(a.std()), rg, float(np.quantile(a, 0.05)), float(np.quantile(a, 0.95))
 
 
 def structure_report(IF, x, e_noe, ref_xyz, ref_rank=1, rows=None):
@@ -141,6 +142,10 @@ def structure_report(IF, x, e_noe, ref_xyz, ref_rank=1, rows=None):
     return dict(assess=assess, rho=rho, order=order, best=best, matched=matched, rho_best=float(rho[best]), rho_matched=float(rho[matched]),
                 rho_mean=float(rho.mean()), rho_ref=float(rho_ref), delta=float(rho[best] - rho_ref),
                 delta_matched=float(rho[matched] - rho_ref),
+                # The bundled model of a chromosome is NOT the reference's energy-best (its file name carries ranks 1..10 of 20): it was
+                # picked from the run, by all appearance for its Spearman (spearman_IF_pdb.pl:73-76 prints the models sorted by it).  The
+                # like-for-like figure is therefore our BEST-SPEARMAN replica; `delta_closest` = the replica nearest to the reference's value
+                delta_max=float(rho.max() - rho_ref), delta_closest=float(rho[np.argmin(np.abs(rho - rho_ref))] - rho_ref), rho_sd=float(rho.std()),
                 ref_percentile=float((rho < rho_ref).mean()),      # fraction of our replicas below the reference's value
                 sim_best=sim_best, sim_matched=sim_match, sim_own=sim_own, chain=ours, chain_ref=ref,
                 rg_ratio=ours[4] / ref[4])

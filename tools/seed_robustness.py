@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How much of the parity table is the seed?  The all-45 sweep for several seeds: per seed the counts within +-0.01 / 0.02 / 0.03, and
-per chromosome mean and spread of dSpearman (best-ranked replica of 20 against the bundled model).
+per chromosome mean and spread of dSpearman (best-ranked replica of 20 against the bundled model), and the same for the BEST-SPEARMAN
+replica of the 20 (the bundled model is not the reference's energy-best: its file name carries ranks 1..10).
     python tools/seed_robustness.py [seeds=82364,1,2,3,4,5,6,7]"""
 import glob, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +28,7 @@ def key(c):
 
 s = Solver(0)
 cids = sorted({os.path.basename(p)[:-len("_upper.npz")] for p in glob.glob(f"{ALL}/*_upper.npz") if "standin" not in np.load(p).files}, key=key)
-D = np.zeros((len(cids), len(seeds)))
+D = np.zeros((len(cids), len(seeds))); DX = np.zeros((len(cids), len(seeds)))
 for ci, cid in enumerate(cids):
     IF = load(cid)
     ref = -pipeline.spearman_IF_pdb(IF, load_pdb(glob.glob(f"{ALL}/{cid}_rank*_a11.pdb")[0]))
@@ -40,16 +41,24 @@ for ci, cid in enumerate(cids):
         rho = -pipeline.spearman_IF_models(IF, s.coords())
         best = int(np.argsort(s.energies()[:, 0].astype(np.int64), kind="stable")[0])
         D[ci, si] = rho[best] - ref
+        DX[ci, si] = rho.max() - ref
 print("| seed | within 0.01 | within 0.02 | within 0.03 | mean abs | max abs | bias |")
 print("|---|---|---|---|---|---|---|")
 for si, seed in enumerate(seeds):
     a = np.abs(D[:, si])
     print(f"| {seed} | {(a <= 0.01).sum()} | {(a <= 0.02).sum()} | {(a <= 0.03).sum()} | {a.mean():.4f} | {a.max():.4f} | {D[:, si].mean():+.4f} |")
 print()
+print("best-Spearman replica of the 20:")
+print("| seed | within 0.01 | within 0.02 | mean abs | max abs | bias |")
+print("|---|---|---|---|---|---|")
+for si, seed in enumerate(seeds):
+    a = np.abs(DX[:, si])
+    print(f"| {seed} | {(a <= 0.01).sum()} | {(a <= 0.02).sum()} | {a.mean():.4f} | {a.max():.4f} | {DX[:, si].mean():+.4f} |")
+print()
 print("| chromosome | mean d | sd over seeds | min | max | seeds within 0.01 |")
 print("|---|---|---|---|---|---|")
 for ci, cid in enumerate(cids):
     d = D[ci]
-    print(f"| {cid} | {d.mean():+.4f} | {d.std():.4f} | {d.min():+.4f} | {d.max():+.4f} | {(np.abs(d) <= 0.01).sum()}/{len(seeds)} |")
+    print(f"| {cid} | {d.mean():+.4f} | {d.std():.4f} | {d.min():+.4f} | {d.max():+.4f} | {(np.abs(d) <= 0.01).sum()}/{len(seeds)} | best-Spearman replica: {DX[ci].mean():+.4f}, {(np.abs(DX[ci]) <= 0.01).sum()}/{len(seeds)} |")
 m = np.abs(D.mean(1))
 print(f"\nseed-averaged d: within 0.01: {(m <= 0.01).sum()}, within 0.02: {(m <= 0.02).sum()}; typical spread over seeds (median sd) {np.median(D.std(1)):.4f}")
