@@ -20,9 +20,12 @@ Nothing is built inside a timed region: one untimed pass replays the identical c
 (hipGraphs of the per-step path are captured there; the multi-step cluster kernel needs none), and
 the library's `graph_captures` counter is asserted unchanged over the timed regions.
 
---scaling weak   (default) every rank runs its own 20 replicas (ids rank*20 ..), no data-path collective
---scaling strong 20 replicas in all, split 3,3,3,3,2,2,2,2 over the ranks (sharding.replica_range):
-                 the north star's "20 replicas of chr1_500kb at 1/2/4/8 MI355X"
+--scaling strong (default for --gpus N > 1) 20 replicas IN ALL, split 3,3,3,3,2,2,2,2 over the ranks (sharding.replica_range):
+                 the north star's "20 replicas of chr1_500kb at 1/2/4/8 MI355X"; the weak figure of the same run rides along
+--scaling weak   (the one-GPU default, where the two coincide) every rank runs its own 20 replicas (ids rank*20 ..)
+Every line with more than one rank — and the one-GPU line — also carries `config4`: all 23 chromosomes at 500 kb x 20 replicas,
+matrices to ranks by LPT, one gather (python -m chromosome3d_amd.batch's code), wall-clock barrier to barrier with the per-rank load;
+the one-GPU line carries `end_to_end`: the user-facing path of chromosome3D.pl for chr1_500kb as a child process (c3d_batch).
 After the timed regions one all_gather (RCCL) of the per-replica records of a COMPLETE untimed anneal
 lets rank 0 rank all models (reported: gather_ms, spearman_*).
 
@@ -188,13 +191,80 @@ def side_figures(device, IF, model, fire, stages, args, B):
     return out
 
 
+def config4_block(s, rank, world, dist, device, sync_all):
+    """All 23 chromosomes at 500 kb x 20 replicas (test.sh:9-12; chr2_500kb is the documented stand-in), matrices to ranks by
+    longest-processing-time-first on their restraint counts, every rank solves its share through the C ABI (full default schedule with the
+    gradient exit, scoring included), ONE gather of the model records, per-chromosome ranking on rank 0: the code of
+    `python -m chromosome3d_amd.batch`, timed barrier to barrier around solve + gather (inputs already parsed: they are resident numpy arrays)."""
+    from chromosome3d_amd import batch, sharding
+    standins = set()
+    mats = batch.load_matrices(os.path.join(ROOT, "tests", "golden", "all45"), "_500kb", standins)
+    costs = batch.job_costs(mats)
+    mine = sharding.lpt_assign(costs, world)[rank]
+    batch.solve_assigned(s, mats, mine[:1], 20)            # first touch of this path (buffers of the largest job), untimed
+    sync_all()
+    t0 = time.perf_counter()
+    rec = batch.solve_assigned(s, mats, mine, 20)
+    t_solve = time.perf_counter() - t0
+    allrec = batch.gather(rec, dist, device)
+    sync_all()
+    wall = time.perf_counter() - t0
+    load = np.array([[float(len(mine)), float(sum(costs[k] for k in mine)), t_solve, float(rec[:, 4].sum()) / 20.0]])
+    loads = batch.gather(load, dist, device)
+    if rank != 0:
+        return None
+    per = batch.rank_per_chromosome(allrec, len(mats))
+    return {"workload": f"{len(mats)} chromosomes at 500 kb x 20 replicas ({len(allrec)} models), LPT over {world} rank(s), one gather",
+            "wall_s": round(wall, 4), "models_per_s": round(len(allrec) / wall, 1), "standins": sorted(standins),
+            "per_rank": [{"chromosomes": int(l[0]), "restraints": int(l[1]), "solve_s": round(float(l[2]), 4), "anneal_device_ms": round(float(l[3]), 2)} for l in loads],
+            "chromosomes_ranked": len(per), "spearman_best_ranked_mean": round(-float(np.mean([r[0, 3] for r in per])), 4),
+            "note": "solve_s = the rank's wall for its chromosomes (K1, 5172-step schedule with gradient exit, read-back, Spearman of 20 models each); "
+                    "wall_s = barrier to barrier incl. the gather; the reference runs this as 23 background processes (test.sh:9-12)"}
+
+
+def end_to_end(IF):
+    """The user-facing path of chromosome3D.pl for the headline matrix, as a child process: c3d_batch on chr1_500kb's text matrix —
+    parse -> K1 -> <ID>.dist/.rr/contact.tbl/.fasta -> 20 start structures -> anneal -> read-back, ranking, Spearman -> 20 PDB files,
+    the reference's satisfaction table (c3d_assess) -> shaping (filter_nonCA/reindex/CONECT) -> <ID>_model1..5.pdb.  The text matrix is
+    written here first (untimed: the reference gets it as its input)."""
+    import re
+    import subprocess
+    import tempfile
+    from tests.util import write_if_text
+    exe = os.path.join(ROOT, "chromosome3d_amd", "_lib", "c3d_batch")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        mat = os.path.join(td, f"{WORKLOAD}_matrix.txt")
+        write_if_text(IF, mat)
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            p = subprocess.run([exe, mat, "--out", os.path.join(td, "out"), "--lanes", "1", "-m", str(REPLICAS)], capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"error": (p.stdout + p.stderr)[-300:]}
+            mm = re.search(r"end-to-end ([0-9.]+) s.*\[phases: parse\+K1 ([0-9.]+), front-half files\+start structures ([0-9.]+), anneal ([0-9.]+), "
+                           r"read-back\+rank\+Spearman ([0-9.]+), PDB\+assessment\+shaping ([0-9.]+) s\]", p.stdout)
+            runs.append((wall, [float(g) for g in mm.groups()] if mm else None))
+        wall, ph = sorted(runs, key=lambda r: r[0])[1]
+        out = {"workload": f"{WORKLOAD} x {REPLICAS} models, c3d_batch --lanes 1 as a child process (median of 3)", "process_wall_s": round(wall, 3)}
+        if ph:
+            out.update({"job_s": ph[0], "phases_s": {"parse_and_K1": ph[1], "front_half_files_and_start_structures": ph[2], "anneal": ph[3],
+                                                      "read_back_rank_spearman": ph[4], "pdb_assessment_shaping": ph[5]},
+                        "process_start_and_device_init_s": round(wall - ph[0], 3)})
+        out["reference_recorded"] = ("chromosome3D.pl on this matrix, measured in the build container on one core (BASELINE.md 2), NOT on this box: Perl front half "
+                                     "3.3 s + assessment 4.5 s per model (90 s for 20); its CNS leg cannot run here")
+        return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=172)
     ap.add_argument("--reps", type=int, default=0, help="timed K-step regions (0 = 50 for K <= 100, else 5)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="default: strong for --gpus N > 1 (20 replicas in all), weak at one GPU")
     ap.add_argument("--dtype", choices=("f32", "f64"), default="f32",
                     help="f64: the fp64 reference step (c3d_f64.hip, written for clarity) instead of the fp32 product kernels")
     ap.add_argument("--dist", action="store_true", help="initialise the torch.distributed process group even at one rank (RCCL path on a one-GPU box)")
@@ -217,6 +287,8 @@ def main():
     dist, coll_dev, local_rank = launch.init_process_group(local_rank, world, force=args.dist)
     torch = sys.modules.get("torch")
     on_gpu_group = coll_dev == "cuda"
+    if args.scaling is None:                      # the north star's case is "20 replicas at 1/2/4/8 GPUs": strong scaling
+        args.scaling = "strong" if world > 1 else "weak"
 
     from chromosome3d_amd import Solver, default_fire, default_model, default_schedule, pipeline, sharding
     from tests.util import load_if
@@ -292,6 +364,7 @@ def main():
             totals["sa_steps"] += did
             totals["launches"] += s.last_timing()[2]
         walls, devs, kerns, launches = [], [], [], 0
+        bbs.clear()
         for _ in range(reps):
             # a region that would cross the end of the schedule starts a fresh batch of replicas first (untimed)
             if pos + args.steps > L and args.steps <= L:
@@ -300,6 +373,7 @@ def main():
                 s.init_replicas(M, 82364, batch * total_replicas + first)
             if timed:
                 sync_all()
+            t_open = time.perf_counter()          # this rank has left the opening bracket
             wall, left, dev, kern = 0.0, args.steps, 0.0, 0.0
             while left > 0:
                 if pos >= L:                                              # only when --steps exceeds the schedule
@@ -327,16 +401,19 @@ def main():
                 if torch.cuda.is_available():
                     torch.cuda.synchronize()
                 dist.barrier()
+            bbs.append(time.perf_counter() - t_open)    # barrier to barrier: the jointly bracketed region (one rank: = the rank's clock + loop bookkeeping)
             walls.append(wall)
             devs.append(dev)
             kerns.append(kern)
         return walls, devs, kerns, launches
 
+    bbs = []
     pattern(False)                                # untimed: every graph the pattern needs exists afterwards
     cap0 = s.stat("graph_captures")
     fb0 = s.stat("resident_fallbacks")
     s.set_option("event_timing", 0)               # nothing but launch + synchronise inside the clock (an event pair costs 2-5 us per call)
     walls, _, _, launches = pattern(True)
+    bb_walls = list(bbs)
     s.set_option("event_timing", 1)
     captures_in_timed = s.stat("graph_captures") - cap0
     fallbacks_in_timed = s.stat("resident_fallbacks") - fb0
@@ -351,9 +428,9 @@ def main():
     path = int(s.stat("last_path"))
 
     if dist is not None:
-        t = torch.tensor([walls, devs, kerns], dtype=torch.float64, device="cuda" if on_gpu_group else "cpu")
+        t = torch.tensor([walls, devs, kerns, bb_walls], dtype=torch.float64, device="cuda" if on_gpu_group else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # per region: the slowest rank
-        walls, devs, kerns = t[0].tolist(), t[1].tolist(), t[2].tolist()
+        walls, devs, kerns, bb_walls = t[0].tolist(), t[1].tolist(), t[2].tolist(), t[3].tolist()
         fw = torch.tensor([full_wall, full_dev_ms, float(M)], dtype=torch.float64, device="cuda" if on_gpu_group else "cpu")
         allfw = [torch.zeros_like(fw) for _ in range(world)]
         dist.all_gather(allfw, fw)
@@ -363,6 +440,7 @@ def main():
     else:
         per_rank = [M]
     wall = statistics.median(walls)
+    bb_wall = statistics.median(bb_walls)
     dev_ms = statistics.median(devs)
     kern_us = statistics.median(kerns)             # 0 on the per-step paths (no single kernel to stamp)
 
@@ -388,6 +466,11 @@ def main():
             ww = tw.tolist()
         weak_value = wt * args.steps / statistics.median(ww)
 
+    # ---- BASELINE configs[3] in every line: all 23 chromosomes at 500 kb x 20 replicas over the ranks (the sharding that scales) ----
+    c4 = None
+    if not args.no_side_figures and args.dtype == "f32":
+        c4 = config4_block(s, rank, world, dist, "cuda" if on_gpu_group else "cpu", sync_all)
+
     if rank == 0:
         value = total_replicas * args.steps / wall
         B = 4 * R + 72 * n                                             # algorithmic bytes per replica-step
@@ -401,7 +484,8 @@ def main():
         achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9     # this rank's GPU: algorithmic bytes of a launch / its duration
         traffic, traffic_src = hbm_traffic_from_profiles(kernel, n, M)
         out = {
-            "metric": "SA-steps/sec (replica-steps/s, 20 replicas of chr1_500kb); wall-clock per chromosome",
+            "metric": f"SA-steps/sec (replica-steps/s, {total_replicas} replicas of chr1_500kb in all: {'+'.join(str(c) for c in per_rank)} per GPU, "
+                      f"{args.scaling} scaling); wall-clock per chromosome",
             "value": round(value, 1),
             "unit": "replica-steps/s",
             "n_gpus": world,
@@ -422,6 +506,12 @@ def main():
                        "launch": {2: "one multi-step cluster launch per region", 0: "eager" if args.no_graph else "hipGraph",
                                   3: "fp64: one k64_step launch per step and replica group, hipGraph"}.get(path, "?")},
             "reps": reps,
+            # two clocks per region, both maxima over the ranks: `value` uses the rank's own (from leaving the opening barrier to the return
+            # of c3d_run_steps, which has waited for the solver's stream: the same interval as at one rank); the jointly bracketed one
+            # (opening barrier -> closing device synchronise + barrier) adds the closing bracket's own latency
+            "timing": {"value_uses": "max over ranks of each rank's clock: opening barrier left -> c3d_run_steps returned",
+                       "barrier_to_barrier_ms": {"median": round(1e3 * bb_wall, 4), "min": round(1e3 * min(bb_walls), 4), "max": round(1e3 * max(bb_walls), 4)},
+                       "value_barrier_to_barrier": round(total_replicas * args.steps / bb_wall, 1)},
             "region_wall_ms": {"median": round(1e3 * wall, 4), "min": round(1e3 * min(walls), 4), "max": round(1e3 * max(walls), 4)},
             "device_ms_per_region": round(dev_ms, 4),
             "us_per_step_device": round(us_per_step_dev, 4),
@@ -463,8 +553,13 @@ def main():
             "spearman_reference_model": 0.8722,
             "e_noe_best": round(float(allrec[order[0], 1]), 1),
         }
+        if c4 is not None:
+            out["config4"] = c4
         if world == 1 and not args.no_side_figures and args.dtype == "f32":
             out.update(side_figures(local_rank, IF, model, fire, stages, args, B))
+            e2e = end_to_end(IF)
+            if e2e is not None:
+                out["end_to_end"] = e2e
         if not args.no_cpu_baseline and world == 1:          # the CPU leg runs on rank 0 of the one-GPU run only
             v, sample, all_cores = cpu_baseline(IF, d10, model, fire, stages)
             out["cpu_baseline"] = {"value": round(v, 1), "unit": "replica-steps/s", "cores": 1, "kind": "port",

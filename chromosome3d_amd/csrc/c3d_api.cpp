@@ -117,6 +117,8 @@ struct c3d_ctx {
     int start_mode = 0;                    // initial structure: 0 random coil, 1 extended strand (reference :2413-2416)
     int resident = -1;                     // multi-step cluster kernel (c3d_cluster.hip): 1 forced, 0 off, -1 where it applies
     int resident_min_ops = 4;              // shorter ranges go step by step
+    double spin_wait_us = 400.0;           // a cluster launch is waited for on its completion mark for this long before hipStreamSynchronize (0: never)
+    long spin_completions = 0;
 
     std::vector<int32_t> h_dist10;   // n*n, from K1 (empty when restraints came from a tbl)
     c3d::DevBuffers buf{};
@@ -441,7 +443,22 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("cluster launch: ") + hipGetErrorString(e));
     if (c->event_timing) HIP_TRY(hipEventRecord(c->ev1, c->stream));    // closes the timed range unless more work follows (end_timing)
     const auto h1 = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // The launch's last workgroup writes its completion mark into host-mapped memory (timeout[1], c3d_cluster.hip): a short launch is
+    // waited for by watching that word — hipStreamSynchronize returns ~6 us after the kernel has ended (profiles/r04_launch_overhead.txt) —
+    // for at most `spin_wait_us`; a longer launch, a time-out or a misplacement goes through the synchronise call as before.  Everything
+    // that touches the results afterwards is ordered on the stream (next launch, copies), so nothing needs the kernel's formal end here.
+    bool marked = false;
+    if (c->spin_wait_us > 0 && !c->kernel_timing) {
+        const unsigned mark = (seq << 20) | 1u;
+        for (;;) {
+            if (__atomic_load_n(&c->h_tmo[1], __ATOMIC_ACQUIRE) == mark) { marked = true; break; }
+            if (__atomic_load_n(&c->h_tmo[0], __ATOMIC_RELAXED) || __atomic_load_n(&c->h_tmo[2], __ATOMIC_RELAXED)) break;
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h1).count() > c->spin_wait_us) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!marked) HIP_TRY(hipStreamSynchronize(c->stream));
+    else ++c->spin_completions;
     const auto h2 = std::chrono::steady_clock::now();
     c->last_host_launch_us += std::chrono::duration<double, std::micro>(h1 - h0).count();
     c->last_host_sync_us += std::chrono::duration<double, std::micro>(h2 - h1).count();
@@ -559,6 +576,7 @@ int end_timing(c3d_ctx* c) {
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (!c->event_timing) return C3D_OK;
+    HIP_TRY(hipEventSynchronize(c->ev1));          // (a launch waited for on its completion mark may not have retired its event yet)
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
@@ -804,6 +822,7 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         free_replica_buffers(c);
         return C3D_OK;
     }
+    if (!strcmp(key, "spin_wait_us")) { c->spin_wait_us = value < 0 ? 0 : value; return C3D_OK; }
     if (!strcmp(key, "resident_min_ops")) { c->resident_min_ops = value < 1 ? 1 : (int)value; return C3D_OK; }
     if (!strcmp(key, "stage_dma")) { c->stage_dma = value != 0; drop_graphs(c); return C3D_OK; }
     if (!strcmp(key, "graph_chunk")) {
@@ -1229,6 +1248,7 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     else if (!strcmp(key, "cluster_launches")) *value = (double)c->cluster_launches;
     else if (!strcmp(key, "resident_fallbacks")) *value = (double)c->resident_fallbacks;
     else if (!strcmp(key, "cluster_incomplete")) *value = (double)c->cluster_incomplete;
+    else if (!strcmp(key, "spin_completions")) *value = (double)c->spin_completions;
     else if (!strcmp(key, "cluster_static_placement")) *value = c->static_place ? 1.0 : 0.0;
     else if (!strcmp(key, "cluster_placement_mismatches")) *value = (double)c->placement_mismatches;
     else if (!strcmp(key, "num_xcc")) *value = (double)c->num_xcc;

@@ -64,6 +64,7 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     std::vector<double> if_copy(IF, IF + (size_t)n * n);
     c3d_free(IF);
     TRY(c3d_set_if_matrix(ctx, if_copy.data(), n, o.alpha, o.K));
+    const double t_k1 = now_s();
     std::vector<int32_t> d10((size_t)n * n);
     TRY(c3d_get_dist10(ctx, d10.data()));
     const std::string tbl = dir + "/contact.tbl";
@@ -81,13 +82,17 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     c3d_default_fire(&fire);
     TRY(c3d_set_schedule(ctx, stages.data(), (int)stages.size(), &fire, (float)o.gtol, 250));
     TRY(c3d_init_replicas(ctx, o.models, o.seed, 0));
+    const double t_front = now_s();
+    double t_anneal0 = t_front;
     {   // one anneal at a time per GPU: the multi-step kernel wants every CU; the host phases of the other lanes run meanwhile.
         // Their short device phases (K1: two kernels of ~20 us, coordinate copies) are NOT serialised: a cluster launch whose
         // workgroups find a CU busy with one of them becomes resident as soon as it drains, microseconds later, far inside
         // the 0.3 s after which a launch gives up (c3d_cluster.hip); the fallback counter stays 0 in profiles/r02_config4_*.
         std::lock_guard<std::mutex> lk(gpu);
+        t_anneal0 = now_s();                        // (the wait for the GPU, when another lane anneals, is not this job's anneal)
         TRY(c3d_run(ctx));
     }
+    const double t_run = now_s();
     double ms = 0;
     long steps = 0, launches = 0;
     c3d_last_timing(ctx, &ms, &steps, &launches);
@@ -99,6 +104,7 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     TRY(c3d_get_energies(ctx, en.data()));
     TRY(c3d_rank(ctx, rank.data()));
     TRY(c3d_spearman_if_dist_batch(if_copy.data(), xyz.data(), n, M, 3, rho.data()));
+    const double t_score = now_s();
     // restraint rows for the satisfaction table (:447-485, :581-600)
     int32_t *pi = nullptr, *pj = nullptr, *pt = nullptr;
     int Rt = 0;
@@ -140,10 +146,13 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     }
     lgc.f = nullptr;
     if (fclose(lg) != 0) { job.summary = "cannot write the log"; return false; }
-    char buf[320];
+    char buf[512];
+    const double t_end = now_s();
     snprintf(buf, sizeof buf, "%-14s N=%4d R=%6d  %2d models  best: replica %2d  E_noe %12.1f  Spearman(IF,1/d) %.4f  anneal %6.1f ms (%ld steps)  "
-                              "end-to-end %.2f s  GPU %d",
-             job.chrom.c_str(), n, R, M, rank[0] + 1, en[3 * rank[0]], -rho[rank[0]], ms, steps, now_s() - t0, job.device);
+                              "end-to-end %.2f s  GPU %d  [phases: parse+K1 %.3f, front-half files+start structures %.3f, anneal %.3f, read-back+rank+Spearman %.3f, "
+                              "PDB+assessment+shaping %.3f s]",
+             job.chrom.c_str(), n, R, M, rank[0] + 1, en[3 * rank[0]], -rho[rank[0]], ms, steps, t_end - t0, job.device, t_k1 - t0, t_front - t_k1,
+             t_run - t_anneal0, t_score - t_run, t_end - t_score);
     job.summary = buf;
     return true;
 }

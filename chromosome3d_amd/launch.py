@@ -7,7 +7,8 @@ The reference's batch is one OS process per matrix (`test.sh:4-12`); here it is 
   set and must equal --gpus, else the run stops with a message instead of quietly measuring something else;
 * plain `python bench.py --gpus N` with N > 1: this process starts the N ranks itself as CHILD processes
   (`torch.distributed.run`), before it has made any HIP or torch.cuda call, relays their output and exits with their status.
-  It never replaces itself (no exec) and never touches the GPU.
+  It never replaces itself (no exec) and never touches the GPU: the GPUs are counted from the KFD topology in sysfs, torch is not
+  even imported in the parent.
 
 `--dist` (or C3D_BENCH_FORCE_DIST=1) makes a single process initialise the process group at world size 1, so that the
 RCCL code path (init, device-side all_gather / all_reduce) also runs on a one-GPU box.
@@ -25,13 +26,33 @@ def free_port():
         return so.getsockname()[1]
 
 
-def visible_gpus():
-    """GPUs this process could use, counted without creating a HIP context (torch.cuda.device_count() only enumerates)."""
+def _index_list(value):
+    return [t for t in value.replace(" ", "").split(",") if t != ""]
+
+
+def visible_gpus(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs a child process will be able to use, counted WITHOUT loading HIP, HSA or torch: the KFD topology nodes with SIMDs
+    (`simd_count > 0` in <node>/properties; CPU nodes have 0), capped by what ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES leave visible.  Returns None when the topology cannot be read (no amdgpu driver in this container, or a
+    sandbox without sysfs): the caller then lets the children find out."""
     try:
-        import torch
-        return int(torch.cuda.device_count())
-    except Exception:
-        return 0
+        nodes = os.listdir(root)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(root, node, "properties")) as fh:
+                for line in fh:
+                    parts = line.split()
+                    if len(parts) == 2 and parts[0] == "simd_count" and int(parts[1]) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            continue
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in os.environ:
+            n = min(n, len(_index_list(os.environ[var])))
+    return n
 
 
 def ensure_ranks(gpus, argv, script=None, module=None, what="bench.py"):
@@ -49,12 +70,12 @@ def ensure_ranks(gpus, argv, script=None, module=None, what="bench.py"):
         return 0, 0, 1
     backend = os.environ.get("C3D_BENCH_BACKEND", "nccl")
     have = visible_gpus()
-    if backend == "nccl" and have < gpus:
+    if backend == "nccl" and have is not None and have < gpus:
         sys.exit(f"{what}: --gpus {gpus} asked for, this machine exposes {have} GPU(s): one rank per GPU over RCCL needs {gpus}. "
                  f"(C3D_BENCH_BACKEND=gloo rehearses the {gpus}-rank code path on the GPUs there are; its timings mean nothing.)")
     target = ["-m", module] if module else [script]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port())] + target + list(argv)
+    # --standalone: torch.distributed.run picks a free rendezvous port itself (no bind / close / reuse race between concurrent launches)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(gpus)] + target + list(argv)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -79,8 +100,10 @@ def init_process_group(local_rank, world, force=False):
         os.environ.setdefault("WORLD_SIZE", "1")
     backend = os.environ.get("C3D_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
-    if backend == "nccl" and ndev < 1:
-        sys.exit("the RCCL process group needs a GPU; none is visible")
+    if backend == "nccl" and ndev < max(world, 1):
+        # (the parent counts GPUs from sysfs; where that is unreadable the ranks find out here)
+        sys.exit(f"--gpus {world} asked for, this machine exposes {ndev} GPU(s): one rank per GPU over RCCL needs {world}. "
+                 f"(C3D_BENCH_BACKEND=gloo rehearses the {world}-rank code path on the GPUs there are; its timings mean nothing.)")
     local = local_rank % max(ndev, 1)
     if ndev:
         torch.cuda.set_device(local)

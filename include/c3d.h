@@ -136,7 +136,9 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *   replica_groups  1..4 stream groups of the per-step path (default 2);  graph_chunk, rows_per_wave,
  *   stage_dma       tuning and test knobs of the per-step kernel
  *   event_timing    1 (default) / 0: HIP-event pair around c3d_run / c3d_run_steps (feeds c3d_last_timing)
- *   kernel_timing   1: start/stop events attached to every multi-step launch (stat "last_kernel_us") */
+ *   kernel_timing   1: start/stop events attached to every multi-step launch (stat "last_kernel_us")
+ *   spin_wait_us    how long c3d_run_steps watches the completion mark a multi-step launch writes into host-mapped memory before it
+ *                   falls back to hipStreamSynchronize (default 400; 0 = always synchronise).  Results are untouched by it. */
 int c3d_set_option(c3d_ctx* ctx, const char* key, double value);
 
 /* --- replicas ----------------------------------------------------------------------- */
@@ -170,7 +172,7 @@ int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* lau
  * captured + instantiated), "graph_launches", "graphs_cached", "step_launches" (k_step dispatches), "resident_launches",
  * "cluster_launches", "resident_fallbacks" (multi-step launches abandoned for the per-step path), "cluster_incomplete"
  * (those of them that ended without every (replica, part) workgroup reporting), "cluster_static_placement",
- * "cluster_placement_mismatches", "num_xcc", "last_path"
+ * "cluster_placement_mismatches", "spin_completions" (multi-step launches whose end was seen on the completion mark), "num_xcc", "last_path"
  * (0 per-step, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "cluster_late_tiles", "last_host_launch_us", "last_host_sync_us" (host time inside the launch / synchronise call of the last c3d_run_steps, cluster launches), "cluster_compute_waves", "replica_groups",
  * "k1_recomputed" (elements of the last c3d_set_if_matrix that sat within 1e-10 of a "%.1f" rounding tie and were redone
  * on the host in the reference's operation order), "k1_patched" (how many of those changed, since c3d_create),

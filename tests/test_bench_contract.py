@@ -30,6 +30,11 @@ def test_driver_arguments_line():
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["unit"] == "replica-steps/s" and d["higher_is_better"] is True and d["dtype"] == "f32"
     assert "chr1_500kb" in d["config"]["workload"] and d["config"]["replicas_per_gpu"] == [20]
+    assert "20 replicas of chr1_500kb in all: 20 per GPU" in d["metric"]
+    # both clocks of a region are in the line; at one rank they differ by the loop's bookkeeping only
+    t = d["timing"]
+    assert t["barrier_to_barrier_ms"]["median"] >= d["region_wall_ms"]["median"] and t["value_barrier_to_barrier"] <= d["value"] * 1.001
+    assert t["value_barrier_to_barrier"] > 0.9 * d["value"]
     assert d["graph_captures_in_timed_regions"] == 0 and d["multi_step_launches_abandoned"] == 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -63,6 +68,14 @@ def test_two_ranks_rehearsal(mode, counts):
     d = _line(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == mode and d["config"]["replicas_per_gpu"] == counts
     assert d["models_ranked"] == sum(counts)
+    assert f"{sum(counts)} replicas of chr1_500kb in all: {counts[0]}+{counts[1]} per GPU, {mode} scaling" in d["metric"]
+    # BASELINE configs[3] rides in every multi-rank line: 23 chromosomes x 20 replicas, LPT over the ranks, one gather
+    c4 = d["config4"]
+    assert c4["chromosomes_ranked"] == 23 and len(c4["per_rank"]) == 2 and sum(r["chromosomes"] for r in c4["per_rank"]) == 23
+    assert c4["standins"] == ["chr2_500kb"] and c4["wall_s"] >= max(r["solve_s"] for r in c4["per_rank"]) > 0
+    ra, rb = (r["restraints"] for r in c4["per_rank"])
+    assert abs(ra - rb) <= 0.15 * (ra + rb)                              # LPT: the two ranks carry about the same restraint count
+    assert d["timing"]["barrier_to_barrier_ms"]["median"] >= d["region_wall_ms"]["median"]
     assert ("weak_scaling_value" in d) == (mode == "strong")
     assert abs(d["spearman_if_invd_best_ranked"] - d["spearman_reference_model"]) <= 0.01
 
@@ -122,7 +135,9 @@ def test_two_ranks_started_by_bench_itself():
                         "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _line(p.stdout)
-    assert d["n_gpus"] == 2 and d["config"]["replicas_per_gpu"] == [20, 20] and d["collective"]["backend"] == "gloo"
+    # no --scaling given: more than one rank defaults to the north star's case, 20 replicas IN ALL; the weak figure rides along
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["replicas_per_gpu"] == [10, 10] and d["collective"]["backend"] == "gloo"
+    assert "weak_scaling_value" in d and "config4" in d and d["config4"]["wall_s"] > 0
 
 
 @pytest.mark.gpu
@@ -132,9 +147,14 @@ def test_side_figures_ride_in_the_one_gpu_line():
                        capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _line(p.stdout)
-    assert 3e5 < d["value_f64"] < d["value"] and 0.01 < d["frac_f64"] < 0.2 and "k64" in d["f64"]["kernel"]
+    assert 1.2e6 < d["value_f64"] < d["value"] and 0.05 < d["frac_f64"] < 0.3 and "k64_step" in d["f64"]["kernel"]
+    assert d["value"] / d["value_f64"] < 3.5                             # round 3: 6.7 x (a naive twin kernel); the fp64 vector rate is half of fp32's
     c2, c5 = d["other_configs"]["config2"], d["other_configs"]["config5"]
     assert c2["n"] == 37 and c2["replicas"] == 20 and 0.5 < c2["us_per_step_device"] < 5.0
     assert c5["n"] == 2500 and c5["replicas"] == 8 and c5["restraints"] == 3113760 and 10.0 < c5["us_per_step_device"] < 60.0
     r = d["roofline"]
     assert r["traffic_unit"] == "bytes per launch" and r["traffic"] == round(r["traffic_bytes_per_sa_step"] * 20)
+    # config 4 on this one GPU and the user-facing path of chromosome3D.pl for the headline matrix as a child process
+    assert d["config4"]["chromosomes_ranked"] == 23 and 0.1 < d["config4"]["wall_s"] < 10.0
+    e = d["end_to_end"]
+    assert 0.05 < e["job_s"] < 10.0 and e["process_wall_s"] >= e["job_s"] and abs(sum(e["phases_s"].values()) - e["job_s"]) < 0.05
