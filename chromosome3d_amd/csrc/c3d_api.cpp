@@ -1381,6 +1381,32 @@ extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
     return C3D_OK;
 }
 
+// Test hook for the one hardware property the cluster kernel's hand-off leans on (c3d_cluster.hip): a 16-byte aligned plain store is never
+// seen half-written by a 16-byte sc1 load of another workgroup.  Runs the producer / consumer pattern of tools/microbench/tear16.hip with the
+// kernel's own store and load on THIS context's stream, all CUs (consumers on the producer's XCD and on every other one).
+extern "C" int c3d_debug_tear16(c3d_ctx* c, int iterations, unsigned long long* unit_reads, unsigned long long* torn, unsigned long long* fresh) {
+    if (!c || iterations < 1 || iterations > (1 << 24)) return fail(C3D_ERR_INVALID, "c3d_debug_tear16: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    DevTmp<unsigned char> buf;
+    DevTmp<unsigned> stop;
+    DevTmp<unsigned long long> stats;
+    HIP_TRY(hipMalloc(&buf.p, 1024 * 16));
+    HIP_TRY(hipMalloc(&stop.p, sizeof(unsigned)));
+    HIP_TRY(hipMalloc(&stats.p, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(buf.p, 0, 1024 * 16, c->stream));
+    HIP_TRY(hipMemsetAsync(stop.p, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(stats.p, 0, 3 * sizeof(unsigned long long), c->stream));
+    hipError_t e = c3d::launch_tear16(c->num_cus, buf.p, stop.p, stats.p, iterations, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("tear16 launch: ") + hipGetErrorString(e));
+    unsigned long long h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (unit_reads) *unit_reads = h[0];
+    if (torn) *torn = h[1];
+    if (fresh) *fresh = h[2];
+    return C3D_OK;
+}
+
 #ifdef C3D_STAMPS
 namespace c3d { hipError_t read_stamps(unsigned long long* out); hipError_t read_cluster_stamps(unsigned long long* out); hipError_t read_cluster_pstamps(unsigned long long* out); }
 extern "C" int c3d_debug_cluster_pstamps(unsigned long long* out) {

@@ -13,15 +13,23 @@
 //
 // and the workgroups of a replica are few and share an XCD:
 //
-//   placement   a workgroup reads HW_REG_XCC_ID and takes a slot from THAT XCD's counter: slot -> (replica, part).
-//               Replica r lives on XCD r % 8 whatever the dispatcher did; a CU without work exits at once.
-//   hand-off    part p publishes per row two 16-byte units {tag, x, tag, y} {tag, z, tag, s} (s = one word of the
-//               8-row tile sums) with PLAIN stores: they write through the CU's L1 into the XCD's L2 and stay there;
-//               every thread gathers its units of the replica's P records with L1-bypassing (sc1) loads until the
-//               tags match.  Producer and consumers share one L2; nothing crosses the fabric.  Measured (tools/
-//               microbench/xcd_handoff.hip, 20 replicas x 10 workgroups): 0.77 us per step, against 1.65 us with
-//               write-through stores and 2.8 us for round 1's 57-records-per-replica form.
+//   placement   (round 3) the dispatcher deals the workgroups of a launch to the XCDs round-robin with an offset that is constant for
+//               the launch, so slot = blockIdx / 8 numbers the workgroups of every XCD: slot -> (replica, part), replica r on XCD r % 8.
+//               Every workgroup checks HW_REG_XCC_ID against blockIdx % 8 and ORs the offset it sees into one word; the completion
+//               mark is refused unless exactly one offset was seen (then: per-step re-run, and the context falls back to round 2's
+//               per-XCD atomic slot counters).  A CU without work exits at once.
+//   hand-off    16-byte units with ONE tag word, published with PLAIN stores (they write through the CU's L1 into the XCD's L2 and
+//               stay there): {tag, x, y, z} per row the moment the row is integrated, then {tag, s0, s1, s2} {tag, s3, 0, 0} per 8-row
+//               tile.  Every thread gathers its row units of the replica's P parts with L1-bypassing (sc1) loads until the tags
+//               match; the tile units are fetched by H0 alone, after the next step has started where the pair loop is long enough
+//               (template parameter LATE).  Producer and consumers share one L2; nothing crosses the fabric.  tag = (launch number
+//               << 20) + step + 1; two record buffers alternate by step parity.  A unit is trusted as a whole once its tag matches:
+//               that a 16-byte aligned store is never seen half-written by a 16-byte load is a property of this hardware, watched by
+//               k_tear16 below (c3d_debug_tear16: the same store, the same load, the solver's stream) in the -m gpu suite.
 //   P == 1      (N <= 64) a replica is one workgroup: no record at all, positions go LDS -> LDS.
+//   completion  every workgroup that finishes its last step bumps a counter; the one that completes replicas x parts writes a mark
+//               into host-mapped memory (no mark -> the host re-runs the range step by step); the host may end its wait on that
+//               mark instead of hipStreamSynchronize (c3d_api.cpp run_cluster, option spin_wait_us).
 //
 // Arithmetic: c3d_step_core.h, every row's force and every sum formed in the order k_step forms it, so a range run
 // here ends in the bits of the per-step path.  Every spin is bounded; a workgroup that gives up sets *timeout and the
@@ -514,6 +522,40 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 hipError_t read_cluster_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamps), sizeof(unsigned long long) * 64 * 8); }
 hipError_t read_cluster_pstamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * 8); }
 #endif
+
+// ---- the hand-off's hardware assumption, watched (c3d_debug_tear16) -----------------------------------------
+// One producer workgroup rewrites 1024 units {i, i, i, i}, i = 1 .. iters, with the plain 16-byte store of the row hand-off; every other
+// workgroup (grid = one per CU: consumers on the producer's XCD and on all others) re-reads them with the sc1 16-byte load of the gather
+// and counts units whose four words differ.  stats: [0] unit reads, [1] torn units, [2] reads that saw a new value.
+__global__ __launch_bounds__(kClMaxThreads) void k_tear16(u32x4* buf, unsigned* stop, unsigned long long* stats, int iters) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(buf, 0, kClMaxThreads * 16, 0x00020000);
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        for (int i = 1; i <= iters; ++i) {
+            u32x4 v; v.x = v.y = v.z = v.w = (unsigned)i;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, tid * 16, 0, 0);
+        }
+        __threadfence();
+        if (tid == 0) atomicExch(stop, 1u);
+        return;
+    }
+    const auto ssrc = __builtin_amdgcn_make_buffer_rsrc(stop, 0, 4, 0x00020000);
+    unsigned long long reads = 0, torn = 0, fresh = 0;
+    unsigned lastv = 0;
+    for (unsigned guard = 0; guard < (1u << 26); ++guard) {                // bounded whatever happens to the producer
+        asm volatile("" ::: "memory");
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, 0, 16);
+        ++reads;
+        if (!(v.x == v.y && v.y == v.z && v.z == v.w)) ++torn;
+        if (v.x != lastv) { ++fresh; lastv = v.x; }
+        if ((reads & 255) == 0 && __builtin_amdgcn_raw_buffer_load_b32(ssrc, 0, 0, 16) != 0u) break;
+    }
+    atomicAdd(&stats[0], reads); atomicAdd(&stats[1], torn); atomicAdd(&stats[2], fresh);
+}
+hipError_t launch_tear16(int num_cus, void* buf, unsigned* stop, unsigned long long* stats, int iters, hipStream_t s) {
+    hipLaunchKernelGGL(k_tear16, dim3(num_cus), dim3(kClMaxThreads), 0, s, reinterpret_cast<u32x4*>(buf), stop, stats, iters);
+    return hipGetLastError();
+}
 
 // ---- host side ---------------------------------------------------------------------------------------
 // Geometry.  A workgroup = CW compute waves x RPW rows (RW = CW * RPW rows, a multiple of 8, at most 64) + 2 or 4 helpers;

@@ -123,6 +123,8 @@ size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl);
 hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout,
                           unsigned* claim, hipStream_t s);
+// the hand-off's 16-byte atomicity, watched: one producer workgroup, one consumer workgroup on every other CU (c3d_cluster.hip k_tear16)
+hipError_t launch_tear16(int num_cus, void* buf, unsigned* stop, unsigned long long* stats, int iters, hipStream_t s);
 // symmetric-tile step for large N (c3d_sym.hip): every pair once.  tiles = sym_tile_list() uploaded, scratch =
 // sym_scratch_floats() floats of device memory (row-side and column-side partial forces of one step).
 void sym_geometry(const DevModel& m, int* Q, int* G, int* ntiles_offdiag, int* ntiles_diag);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "c3d_last_timing": (_i, [_vp, _dp, C.POINTER(_l), C.POINTER(_l)]),
     "c3d_get_stat": (_i, [_vp, C.c_char_p, _dp]),
     "c3d_step_kernel_name": (C.c_char_p, [_vp]),
+    "c3d_debug_tear16": (_i, [_vp, _i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "c3d_eval": (_i, [_vp, _f, _f, _f, _fp, _dp]),
     "c3d_get_energies": (_i, [_vp, _dp]),
     "c3d_score_replicas": (_i, [_vp, _dp, _i, _i32p, _dp, _dp]),

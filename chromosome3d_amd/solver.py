@@ -145,6 +145,12 @@ class Solver:
         _l.check(self._L.c3d_get_stat(self._h, key.encode(), C.byref(v)))
         return v.value
 
+    def debug_tear16(self, iterations=200000):
+        """(unit reads, torn units, reads that saw a new value) of the hand-off's 16-byte store / load pair (c3d_debug_tear16)."""
+        a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+        _l.check(self._L.c3d_debug_tear16(self._h, iterations, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     @property
     def step_kernel_name(self):
         return self._L.c3d_step_kernel_name(self._h).decode()

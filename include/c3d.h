@@ -179,6 +179,11 @@ int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* lau
  * "rms_force" (largest RMS force component over the replicas at the last minimiser step: the quantity c3d_run holds
  * against gtol, the stand-in for L-BFGS's convergence test of chromosome3D.pl:1800-1803). */
 int c3d_get_stat(const c3d_ctx* ctx, const char* key, double* value);
+/* Test hook, no reference counterpart: the multi-step kernel's hand-off trusts a 16-byte unit once its tag word matches — i.e. that a
+ * 16-byte aligned store is never observed half-written by a 16-byte load on gfx950.  This runs that exact store / load pair (one producer
+ * workgroup, a consumer workgroup on every other CU, the context's stream) for `iterations` rewrites of 1024 units and returns the number
+ * of unit reads, of TORN units (must be 0) and of reads that saw a new value. */
+int c3d_debug_tear16(c3d_ctx* ctx, int iterations, unsigned long long* unit_reads, unsigned long long* torn, unsigned long long* fresh);
 /* Name of the step kernel the last c3d_run / c3d_run_steps ran on, as a profiler prints it (thread-local string). */
 const char* c3d_step_kernel_name(const c3d_ctx* ctx);
 

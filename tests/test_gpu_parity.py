@@ -726,6 +726,51 @@ def test_tile_sums_fetched_late_or_gathered_with_the_rows_end_in_the_same_bits(s
         assert np.array_equal(out["late"][0], out[mode][0]) and np.array_equal(out["late"][1], out[mode][1]), mode
 
 
+def test_hand_off_units_are_never_seen_torn(solver):
+    """The multi-step kernel trusts a 16-byte hand-off unit {tag, x, y, z} once its ONE tag word matches: a torn 16-byte access would hand
+    a consumer a new tag with an old coordinate — a silently wrong trajectory.  c3d_debug_tear16 runs that exact pair (plain
+    buffer_store_b128, sc1 buffer_load_b128, 16-byte aligned units) on the solver's stream: one producer workgroup rewrites 1024 units
+    200 000 times while a consumer workgroup on every other CU — its own XCD and the seven others — re-reads them.  0 torn units among
+    ~1e9 observations (tools/microbench/tear16.hip is the stand-alone twin: 1.8e9, 0 torn); runs in well under two seconds."""
+    import time
+    t0 = time.time()
+    reads, torn, fresh = solver.debug_tear16(200000)
+    assert torn == 0, (reads, torn, fresh)
+    assert reads > 5e7 and fresh > 1e6, (reads, fresh)        # the consumers did watch the units change
+    assert time.time() - t0 < 5.0
+    print(f"tear16: {reads:.3g} unit reads, {fresh:.3g} saw a new value, {torn} torn")
+
+
+def test_random_problems_two_contexts_at_once(built):
+    """Eight seconds of the same fuzz in TWO contexts on two host threads sharing the GPU (what c3d_batch's lanes do): a multi-step launch
+    whose workgroups are not all resident because the other context holds CUs is abandoned and re-run step by step — results must be the
+    per-step path's bits regardless, in both contexts, with both hand-off forms of the tile sums alternating."""
+    import sys as _sys
+    import threading
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from chromosome3d_amd import Solver
+    from fuzz_cluster import fuzz
+    out = [None, None]
+    msgs = [[], []]
+
+    def work(k):
+        s = Solver(0)
+        try:
+            out[k] = fuzz(s, seed=777 + k, seconds=8.0, out=msgs[k].append, fallbacks_are_bad=False)
+        finally:
+            s.close()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert out[k] is not None, msgs[k]
+        it, bad, kernels = out[k]
+        assert bad == 0, msgs[k]
+        assert it >= 30 and any("k_cluster" in name for name in kernels), (it, sorted(kernels))
+
+
 def test_random_problems_cluster_kernel_equals_per_step_kernel(solver):
     """Eight seconds of tools/fuzz_cluster.py (random sizes, replica counts, chunkings, either hand-off form): same bits, no abandoned
     launch.  The long run is in tools/: 16 463 problems, 36 instantiations of k_cluster, 0 differences."""

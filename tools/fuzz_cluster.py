@@ -10,7 +10,8 @@ from chromosome3d_amd import Solver, default_model, make_stages, pipeline
 from tests.util import synthetic_if
 
 
-def fuzz(s, seed=1, seconds=60.0, out=print):
+def fuzz(s, seed=1, seconds=60.0, out=print, fallbacks_are_bad=True):
+    """fallbacks_are_bad=False: another context shares the GPU, abandoned launches (re-run step by step) are expected; only the bits count."""
     rng = np.random.default_rng(seed)
     t0 = time.time(); it = 0; bad = 0; kernels = {}; t_note = t0
     while time.time() - t0 < seconds:
@@ -34,7 +35,7 @@ def fuzz(s, seed=1, seconds=60.0, out=print):
         same = np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
         for name in res[1][2]:
             kernels[name] = kernels.get(name, 0) + 1
-        if not same or res[1][3] or res[1][4]:
+        if not same or (fallbacks_are_bad and (res[1][3] or res[1][4])):
             bad += 1
             out(f"{'MISMATCH' if not same else 'FALLBACK'} n={n} replicas={nrep} late={late} stages={k} {sorted(res[1][2])} fallbacks={res[1][3]} incomplete={res[1][4]}")
         it += 1
