@@ -104,7 +104,7 @@ struct c3d_ctx {
     float gtol = 0.0f;
     int check_every = 250;
     bool narrow_columns = true;            // option "narrow_columns" 0: every block 4 columns per lane (round 2's layout; measurements)
-    bool zero_weight = false;              // some stage has w_all = 0: its steps take the general kernels, no cluster launches
+    bool zero_weight = false;              // some stage has w_all = 0: ITS steps take the general kernels (run_ops splits the range there)
     bool use_graph = true;
     int rpw = 2;
     int stage_dma = 1;
@@ -167,6 +167,7 @@ struct c3d_ctx {
     long k1_recomputed = 0, k1_patched = 0;   // K1: near-tie elements redone on the host in the reference's order / changed by it
     long graph_captures = 0, graph_launches = 0, step_launches = 0, resident_launches = 0, cluster_launches = 0;
     int last_path = 0;                     // 0 per-step, 2 k_cluster, 3 fp64 reference (what the last run_ops used)
+    bool last_general = false;             // the last per-step launch took the general-form kernel (general tails, or an op without restraint weight)
 
     double last_ms = 0;
     long last_steps = 0, last_launches = 0;
@@ -371,16 +372,17 @@ int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
         if (e64 != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 step launch: ") + hipGetErrorString(e64));
         return C3D_OK;
     }
+    c->last_general = general_step(m, op.p);
     hipError_t e = use_sym(c) ? c3d::launch_step_sym(m, op.p, dev_fire(c), c->buf, par, c->d_sym_tiles, c->d_sym_scratch, c->gstream[g])
-                              : c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, general_step(m, op.p), c->gstream[g]);
+                              : c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, c->last_general, c->gstream[g]);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
     return C3D_OK;
 }
 
 // Can the ops run as one k_cluster launch (a replica on a few 1024-thread workgroups of one XCD)?
 bool cluster_ok(c3d_ctx* c) {
-    if (!c->resident || !c->cluster || !c->cl_ok || !c->d_crec || c->zero_weight) return false;
-    return !general_tail(dev_model(c));
+    if (!c->resident || !c->cluster || !c->cl_ok || !c->d_crec) return false;
+    return !general_tail(dev_model(c));        // (ops without restraint weight never get here: run_ops splits the range at them)
 }
 
 // after a multi-step launch: did a workgroup give up (or was that injected)?  The launch reads parity p and writes
@@ -478,9 +480,26 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
 
 // run program ops [pc, pc + nops): eager or via cached graphs; every replica group advances on its
 // own stream (fork from / join into stream 0 around the call)
+int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w);
+
+// A stage without restraint weight (w_all = 0: the clamp form divides by it) takes the general kernels; the ops around it keep the
+// multi-step launches: the range is split where the weight changes between zero and non-zero.
 int run_ops(c3d_ctx* c, size_t nops) {
+    if (!c->zero_weight || c->precision == 64) return run_ops_segment(c, nops, false);
+    const size_t end = c->pc + nops;
+    while (c->pc < end) {
+        const bool z = c->program[c->pc].p.w_rs == 0.0f;
+        size_t k = 1;
+        while (c->pc + k < end && (c->program[c->pc + k].p.w_rs == 0.0f) == z) ++k;
+        const int rc = run_ops_segment(c, k, z);
+        if (rc) return rc;
+    }
+    return C3D_OK;
+}
+
+int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w) {
     if (nops == 0) return C3D_OK;
-    if (c->precision == 64) { }                                           // fp64: the per-step path below (k64_step), never the cluster kernel
+    if (c->precision == 64 || zero_w) { }                                           // fp64: the per-step path below (k64_step), never the cluster kernel
     else if (c->resident_skip > 0 && c->resident < 1) --c->resident_skip;     // cooling off after an abandoned launch
     else if (nops >= (size_t)c->resident_min_ops && nops < ((size_t)1 << 20)) {
         bool ran = false;
@@ -1280,7 +1299,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     static thread_local char buf[96];
     if (!c) return "";
     const c3d::DevModel m = dev_model(c);
-    const char* gen = (general_tail(m) || c->zero_weight) ? "true" : "false";
+    const char* gen = (general_tail(m) || c->last_general) ? "true" : "false";     // of the last op launched on the per-step path
     const char* rs1 = (!general_tail(m) && m.rs == 1.0f) ? "true" : "false";
     if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %d, %s>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, m.wl, c->cl_plan.late_tiles ? "true" : "false");
     else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);

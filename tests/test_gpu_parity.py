@@ -726,6 +726,26 @@ def test_tile_sums_fetched_late_or_gathered_with_the_rows_end_in_the_same_bits(s
         assert np.array_equal(out["late"][0], out[mode][0]) and np.array_equal(out["late"][1], out[mode][1]), mode
 
 
+def test_a_stage_without_restraint_weight_does_not_switch_the_cluster_kernel_off(solver):
+    """One stage with w_all = 0 (repel and nothing else: the clamp form cannot express it) takes the general per-step kernel; the stages
+    around it still run as multi-step launches (the range is split where the weight changes), and the whole schedule ends in the bits
+    of the per-step path.  The reported kernel name is that of the last launch, not a property of the whole program."""
+    stages = [(2, 30, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 40, 0.003, 0.0, 1.0, 0.9, 2000.0), (0, 40, 0.003, 0.4, 0.003, 0.9, 2000.0), (2, 40, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    res = {}
+    for resident in (0, -1):
+        _setup(solver, "chr13_1mb", stages, nrep=8)
+        solver.set_option("resident", resident)
+        c0, s0 = solver.stat("cluster_launches"), solver.stat("step_launches")
+        assert solver.run_steps(70) == 70                  # ends inside the zero-weight stage
+        name_mid = solver.step_kernel_name
+        assert solver.run_steps(10 ** 6) == 80
+        res[resident] = (solver.coords(), solver.velocities(), solver.stat("cluster_launches") - c0, solver.stat("step_launches") - s0, name_mid, solver.step_kernel_name)
+    solver.set_option("resident", -1)
+    assert res[0][2] == 0 and res[-1][2] >= 2 and res[-1][3] > 0, res[-1][2:4]          # cluster launches around, step launches inside
+    assert "k_step<" in res[-1][4] and ", true," in res[-1][4] and "k_cluster<" in res[-1][5], res[-1][4:]
+    assert np.array_equal(res[0][0], res[-1][0]) and np.array_equal(res[0][1], res[-1][1])
+
+
 def test_hand_off_units_are_never_seen_torn(solver):
     """The multi-step kernel trusts a 16-byte hand-off unit {tag, x, y, z} once its ONE tag word matches: a torn 16-byte access would hand
     a consumer a new tag with an old coordinate — a silently wrong trajectory.  c3d_debug_tear16 runs that exact pair (plain
