@@ -62,9 +62,9 @@ def job_costs(mats):
     return [(m.shape[0] - 5) * (m.shape[0] - 4) // 2 for m in mats.values()]
 
 
-def solve_assigned(solver, mats, mine, models=20, seed=82364, min_steps=3000, gtol=1e-2, out=None):
+def solve_assigned(solver, mats, mine, models=20, seed=82364, min_steps=3000, gtol=1e-2, out=None, on_job=None):
     """Solve the chromosomes with indices `mine`; returns records [len(mine) * models, 5]:
-    chromosome index, replica, E_noe, Spearman(IF, d), anneal ms."""
+    chromosome index, replica, E_noe, Spearman(IF, d), anneal ms.  on_job(cid, solver) is called after every anneal (bookkeeping hooks)."""
     cids = list(mats)
     recs = []
     for k in mine:
@@ -74,6 +74,8 @@ def solve_assigned(solver, mats, mine, models=20, seed=82364, min_steps=3000, gt
         solver.set_schedule(default_schedule(min_steps), None, gtol, 250)
         solver.init_replicas(models, seed, 0)
         solver.run()
+        if on_job:
+            on_job(cid, solver)
         x, e = solver.coords(), solver.energies()
         rho = pipeline.spearman_IF_models(IF, x)
         r = np.zeros((models, 5))

@@ -195,7 +195,7 @@ void free_replica_buffers(c3d_ctx* c) {
     c->crec_bytes = 0; c->cl_ok = false;
     dev_free(c->buf.Vinit); dev_free(c->buf.E); dev_free(c->d_feval);
     dev_free(c->d_sym_scratch); dev_free(c->d_sym_tiles);
-    dev_free(c->b64.T); dev_free(c->b64.Vinit);
+    dev_free(c->b64.T); dev_free(c->b64.t10); dev_free(c->b64.Vinit);
     for (int k = 0; k < 2; ++k) { dev_free(c->b64.X[k]); dev_free(c->b64.V[k]); dev_free(c->b64.P[k]); dev_free(c->b64.S[k]); }
     c->have_replicas = false;
 }
@@ -357,15 +357,30 @@ bool use_sym(const c3d_ctx* c) {
     return c->sym > 0;
 }
 
+void model_host64(const c3d_ctx* c, double (&mh)[15]) {
+    const c3d_model& h = c->model;
+    const double v[15] = {h.s_noe, h.rswitch, h.asym, h.masym, h.mrswitch, h.k_bond, h.b0, h.k_ang, h.a0, h.r0_rep, h.k_rep, h.mass, h.fbeta,
+                          (double)h.min_sep, (double)h.msoexp};
+    for (int k = 0; k < 15; ++k) mh[k] = v[k];
+}
+// fp64 target matrix from the resident integer tenths, in the encoding the current model's kernel expects (c3d_f64.hip pair64)
+int build_targets64(c3d_ctx* c) {
+    double mh[15];
+    model_host64(c, mh);
+    hipError_t e = c3d::launch_targets64(dev_model(c), mh, c->model.min_sep, c->b64.t10, c->b64.T, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 targets: ") + hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C3D_OK;
+}
+
 // one SA-step launch for replica group g, reading parity `par`
 int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
     c3d::DevModel m = dev_model(c);
     group_range(c, g, m.rep_base, m.nrep_g);
     if (c->precision == 64) {              // the stage's own doubles, not the floats of DevStep
-        const c3d_model& h = c->model;
         const c3d_stage& st = c->stages[op.stage];
-        const double mh[15] = {h.s_noe, h.rswitch, h.asym, h.masym, h.mrswitch, h.k_bond, h.b0, h.k_ang, h.a0, h.r0_rep, h.k_rep, h.mass, h.fbeta,
-                               (double)h.min_sep, (double)h.msoexp};
+        double mh[15];
+        model_host64(c, mh);
         const double fh[7] = {c->fire.dt_start, c->fire.dt_max, c->fire.f_inc, c->fire.f_dec, c->fire.alpha_start, c->fire.f_alpha, c->fire.max_step};
         const double sh[6] = {(double)op.p.kind, st.dt, st.w_all, st.w_vdw, st.repel_s, st.t_bath};
         hipError_t e64 = c3d::launch_step64(m, mh, sh, fh, c->fire.n_min, c->b64, par, c->gstream[g]);
@@ -776,6 +791,7 @@ extern "C" int c3d_set_model(c3d_ctx* c, const c3d_model* m) {
         return fail(C3D_ERR_INVALID, "c3d_set_model: min_sep must be set before the targets are built");
     c->model = *m;
     build_program(c);
+    if (c->precision == 64 && c->b64.T) return build_targets64(c);     // the fp64 target matrix encodes "no restraint" per potential
     return C3D_OK;
 }
 
@@ -1073,13 +1089,9 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
         const int np = c3d::cols64(n);
         const size_t n3 = (size_t)nrep * 3 * np, nP = (size_t)nrep * c->ntiles * 4;
         if (!c->b64.T) {
-            DevTmp<int32_t> t10;
-            HIP_TRY(hipMalloc(&t10.p, sizeof(int32_t) * (size_t)n * n));
-            HIP_TRY(hipMemcpyAsync(t10.p, c->h_dist10.data(), sizeof(int32_t) * (size_t)n * n, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMalloc(&c->b64.t10, sizeof(int32_t) * (size_t)n * n));
+            HIP_TRY(hipMemcpyAsync(c->b64.t10, c->h_dist10.data(), sizeof(int32_t) * (size_t)n * n, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMalloc(&c->b64.T, sizeof(double) * (size_t)n * np));
-            hipError_t e = c3d::launch_targets64(dev_model(c), c->model.min_sep, t10.p, c->b64.T, c->stream);
-            if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 targets: ") + hipGetErrorString(e));
-            HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMalloc(&c->b64.Vinit, sizeof(double) * n3));
             for (int k = 0; k < 2; ++k) {
                 HIP_TRY(hipMalloc(&c->b64.X[k], sizeof(double) * n3));
@@ -1097,7 +1109,9 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
             HIP_TRY(hipMemsetAsync(c->b64.P[k], 0, sizeof(double) * nP, c->stream));
             HIP_TRY(hipMemsetAsync(c->b64.S[k], 0, c3d::fire_state64_bytes() * nrep, c->stream));
         }
-        int rc = import64(c);
+        int rc = build_targets64(c);                // every time: the model may have changed since the last call
+        if (rc) return rc;
+        rc = import64(c);
         if (rc) return rc;
     }
     return C3D_OK;

@@ -48,6 +48,7 @@ constexpr int kRows64 = 2;                       // rows per wave
 constexpr int kWaves64 = kTileRows / kRows64;    // 4 waves: one tile of 8 rows per workgroup (the fp32 step's tile)
 constexpr int kBlock64 = 64 * kWaves64;
 constexpr int kColPad64 = 128;                   // columns padded to two per lane
+constexpr double kNoTarget64 = 1.0e300;          // "no restraint" in the target matrix of the fast soft lower side (pair64)
 
 // ---- 64-bit values through the 32-bit cross-lane paths (DPP, permlane swaps): VALU only, no LDS round trip ----------
 template <int CTRL>
@@ -147,7 +148,11 @@ __device__ __forceinline__ void pair64(const Model64& m, double nws4, double wr4
     const double r2 = fmax(fma(dx, dx, fma(dy, dy, dz * dz)), 1e-12);
     double d, h;
     sqrt_hrsqrt64(r2, d, h);
-    const double wn = T > 0.0 ? nws4 : 0.0;
+    double wn = nws4;
+    // no restraint: T = 0 and the weight is switched off — except for the fast soft lower side (POT 4), where such a pair carries
+    // T = kNoTarget64 = 1e300 instead: a pair that far inside its "target" feels exactly nothing (D = 1e300: the fp32 seed of 1 / D is 0, the
+    // Newton steps keep it, the bound is -0, the force +0), which saves the compare and the two selects of every pair term
+    if constexpr (!(POT == 4 && !GEN)) wn = T > 0.0 ? nws4 : 0.0;
     const double cn = wn * (half_noe_grad64<POT, GEN>(m, d - T) * h);
     const double coef = fma(wr4, fmax(R2 - r2, 0.0), cn);
     fx = fma(coef, dx, fx); fy = fma(coef, dy, fy); fz = fma(coef, dz, fz);
@@ -161,10 +166,11 @@ __device__ __forceinline__ void chain64(const Model64& m, const Step64& p, doubl
     if (row >= m.n || jn < 0 || jn >= m.n) return;
     const double dx = xs[row] - xs[jn], dy = ys[row] - ys[jn], dz = zs[row] - zs[jn];
     const double r2 = fmax(fma(dx, dx, fma(dy, dy, dz * dz)), 1e-12);
-    const double d = sqrt(r2);
+    double d, h;
+    sqrt_hrsqrt64(r2, d, h);                          // h = 1 / (2 d)
     double coef = 0.0;
-    if (sep == 1) coef = -p.w_all * 2.0 * m.k_bond * (d - m.b0) / d;
-    else if (m.k_ang > 0 && (m.ang_mode == 1 || r2 < m.a0 * m.a0)) coef = -p.w_all * 2.0 * m.k_ang * (d - m.a0) / d;
+    if (sep == 1) coef = -p.w_all * 4.0 * m.k_bond * (d - m.b0) * h;
+    else if (m.k_ang > 0 && (m.ang_mode == 1 || r2 < m.a0 * m.a0)) coef = -p.w_all * 4.0 * m.k_ang * (d - m.a0) * h;
     if (sep < m.rep_sep) coef -= wr4 * fmax(R2 - r2, 0.0);      // the pair loop applied the repel term to every column
     cx = coef * dx; cy = coef * dy; cz = coef * dz;
 }
@@ -188,35 +194,41 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
     const size_t roff = (size_t)rep * 3 * np;
     // ---- stage the replica's coordinates; the previous step's sums meanwhile ----
     for (int b = 2 * tid; b < 3 * np; b += 2 * kBlock64) *reinterpret_cast<double2*>(sm64 + b) = *reinterpret_cast<const double2*>(xin + roff + b);
-    const bool needs = p.kind == 0 || p.kind == 1 || p.kind == 2;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (needs) {
-        const double* pp = pin + (size_t)rep * m.ntiles * 4;
-        for (int t = lane; t < m.ntiles; t += 64) { s0 += pp[4 * t]; s1 += pp[4 * t + 1]; s2 += pp[4 * t + 2]; s3 += pp[4 * t + 3]; }
-        s0 = wave_sum64(s0); s1 = wave_sum64(s1); s2 = wave_sum64(s2); s3 = wave_sum64(s3);
-    }
-    // ---- the replica's scalars of this step (every wave derives the same values) ----
-    double lam = 1.0, cm0 = 0, cm1 = 0, cm2 = 0, keep = 0.0, mix = 0.0;
+    // ---- the replica's scalars of this step: ONE wave forms them (the sums of 57 tiles through four butterflies, six fp64 divisions and
+    //      a square root are ~400 instruction slots — as much as two thirds of a wave's pair loop) and leaves them in LDS before the
+    //      barrier everybody waits at anyway ----
+    double* scal = rowq + 4 * kTileRows;                // [8] lam, cm0, cm1, cm2, keep, mix, dt, (unused)
     FireState64 st;
     st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0;
-    if (p.kind == 0 || p.kind == 1) {
-        const int ndf = 3 * n - 3;
-        double tprev = m.mass * s0 / kAccel64 / ((ndf > 0 ? ndf : 1) * kBoltz64);
-        if (tprev < 1e-2) tprev = 1e-2;
-        if (p.kind == 0) { double l2 = 1.0 + p.dt * m.fbeta * (p.t_bath / tprev - 1.0); if (l2 < 0) l2 = 0; lam = sqrt(l2); }
-        else lam = sqrt(p.t_bath / tprev);
-        cm0 = s1 / n; cm1 = s2 / n; cm2 = s3 / n;
-    } else if (p.kind == 2 || p.kind == 3) {
-        if (p.kind == 2) st = sin[rep];
-        if (s0 > 0) {                               // power of the previous evaluation positive (kind 3: sums are 0)
-            keep = 1.0 - st.alpha;
-            mix = st.alpha * sqrt(s2 / (s1 > 1e-30 ? s1 : 1e-30));
-            if (st.npos > fp.n_min) { st.dt = st.dt * fp.f_inc < fp.dt_max ? st.dt * fp.f_inc : fp.dt_max; st.alpha *= fp.f_alpha; }
-            st.npos += 1;
-        } else {
-            st.alpha = fp.alpha_start; st.dt *= fp.f_dec; st.npos = 0;
+    if (wave == 0) {
+        const bool needs = p.kind == 0 || p.kind == 1 || p.kind == 2;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        if (needs) {
+            const double* pp = pin + (size_t)rep * m.ntiles * 4;
+            for (int t = lane; t < m.ntiles; t += 64) { s0 += pp[4 * t]; s1 += pp[4 * t + 1]; s2 += pp[4 * t + 2]; s3 += pp[4 * t + 3]; }
+            s0 = wave_sum64(s0); s1 = wave_sum64(s1); s2 = wave_sum64(s2); s3 = wave_sum64(s3);
         }
-        if (tile == 0 && tid == 0) sout[rep] = st;
+        double lam = 1.0, cm0 = 0, cm1 = 0, cm2 = 0, keep = 0.0, mix = 0.0;
+        if (p.kind == 0 || p.kind == 1) {
+            const int ndf = 3 * n - 3;
+            double tprev = m.mass * s0 / kAccel64 / ((ndf > 0 ? ndf : 1) * kBoltz64);
+            if (tprev < 1e-2) tprev = 1e-2;
+            if (p.kind == 0) { double l2 = 1.0 + p.dt * m.fbeta * (p.t_bath / tprev - 1.0); if (l2 < 0) l2 = 0; lam = sqrt(l2); }
+            else lam = sqrt(p.t_bath / tprev);
+            cm0 = s1 / n; cm1 = s2 / n; cm2 = s3 / n;
+        } else if (p.kind == 2 || p.kind == 3) {
+            if (p.kind == 2) st = sin[rep];
+            if (s0 > 0) {                               // power of the previous evaluation positive (kind 3: sums are 0)
+                keep = 1.0 - st.alpha;
+                mix = st.alpha * sqrt(s2 / (s1 > 1e-30 ? s1 : 1e-30));
+                if (st.npos > fp.n_min) { st.dt = st.dt * fp.f_inc < fp.dt_max ? st.dt * fp.f_inc : fp.dt_max; st.alpha *= fp.f_alpha; }
+                st.npos += 1;
+            } else {
+                st.alpha = fp.alpha_start; st.dt *= fp.f_dec; st.npos = 0;
+            }
+            if (tile == 0 && lane == 0) sout[rep] = st;
+        }
+        if (lane == 0) { scal[0] = lam; scal[1] = cm0; scal[2] = cm1; scal[3] = cm2; scal[4] = keep; scal[5] = mix; scal[6] = st.dt; }
     }
     __syncthreads();
 
@@ -258,6 +270,8 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
         if (lane == 1) { Fx += ox; Fy += oy; Fz += oz; }
     }
     // ---- lanes 0, 1 finish one row each (the CPU restatement's update, c3o_md_step / c3o_fire_step) ----
+    const double lam = scal[0], cm0 = scal[1], cm1 = scal[2], cm2 = scal[3], keep = scal[4], mix = scal[5];
+    st.dt = scal[6];
     const int row = row0 + lane;
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     if (lane < kRows64 && row < n) {
@@ -297,10 +311,10 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
 }
 
 // T[i][j] = 0.1 * t10 where a restraint exists (|i-j| >= min_sep, t10 > 0), else 0; np columns per row
-__global__ __launch_bounds__(256) void k64_targets(int n, int np, int min_sep, const int32_t* __restrict__ t10, double* __restrict__ T) {
+__global__ __launch_bounds__(256) void k64_targets(int n, int np, int min_sep, double none, const int32_t* __restrict__ t10, double* __restrict__ T) {
     const int i = blockIdx.x;
     for (int j = threadIdx.x; j < np; j += 256) {
-        double v = 0.0;
+        double v = none;
         if (j < n) {
             const int sep = j > i ? j - i : i - j;
             const int32_t t = t10[(size_t)i * n + j];
@@ -366,7 +380,7 @@ hipError_t launch_step64(const DevModel& d, const double* model_host, const doub
     fp.f_alpha = fire_host[5]; fp.max_step = fire_host[6]; fp.n_min = fire_n_min;
     const int q = parity ^ 1;
     const dim3 grid(d.ntiles, d.nrep_g), blk(kBlock64);
-    const size_t lds = sizeof(double) * ((size_t)3 * m.np + 4 * kTileRows);
+    const size_t lds = sizeof(double) * ((size_t)3 * m.np + 4 * kTileRows + 8);
     FireState64* sin = reinterpret_cast<FireState64*>(b.S[parity]);
     FireState64* sout = reinterpret_cast<FireState64*>(b.S[q]);
 #define C3D_STEP64(POT, GEN) hipLaunchKernelGGL((k64_step<POT, GEN>), grid, blk, lds, s, m, p, fp, d.rep_base, b.T, b.X[parity], b.V[parity], b.Vinit, \
@@ -380,8 +394,10 @@ hipError_t launch_step64(const DevModel& d, const double* model_host, const doub
 #undef C3D_STEP64
     return hipGetLastError();
 }
-hipError_t launch_targets64(const DevModel& d, int min_sep, const int32_t* t10, double* T, hipStream_t s) {
-    hipLaunchKernelGGL(k64_targets, dim3(d.n), dim3(256), 0, s, d.n, cols64(d.n), min_sep, t10, T);
+hipError_t launch_targets64(const DevModel& d, const double* model_host, int min_sep, const int32_t* t10, double* T, hipStream_t s) {
+    const Model64 m = model64(d, model_host);
+    const double none = (m.noe_pot == 4 && !general64(m)) ? kNoTarget64 : 0.0;        // what pair64 of the kernel that will run expects
+    hipLaunchKernelGGL(k64_targets, dim3(d.n), dim3(256), 0, s, d.n, cols64(d.n), min_sep, none, t10, T);
     return hipGetLastError();
 }
 hipError_t launch_import64(const DevModel& d, const float* Xf, const Buffers64& b, hipStream_t s) {

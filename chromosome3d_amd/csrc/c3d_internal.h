@@ -139,6 +139,7 @@ hipError_t launch_step_sym(const DevModel& m, const DevStep& p, const DevFire& f
 // Layouts (np = cols64(n): n rounded up to 128): T [n][np] targets in Angstrom (0.1 * t10, 0 = none); X, V [2][nrep][3][np] SoA;
 // Vinit [nrep][3][np]; P [2][nrep][ntiles][4] per-tile sums; S [2][nrep] x fire_state64_bytes().
 struct Buffers64 {
+    int32_t* t10 = nullptr;        // the integer tenths T is (re)built from whenever the model changes
     double* T = nullptr;
     double* X[2] = {nullptr, nullptr};
     double* V[2] = {nullptr, nullptr};
@@ -150,7 +151,7 @@ int cols64(int n);
 constexpr int kMaxBeads64 = 2560;     // 3 * 8 * np bytes of LDS must stay below the 64 KB a launch gets without opt-in
 hipError_t launch_step64(const DevModel& d, const double* model_host, const double* step_host, const double* fire_host, int fire_n_min,
                          const Buffers64& b, int parity, hipStream_t s);
-hipError_t launch_targets64(const DevModel& d, int min_sep, const int32_t* t10, double* T, hipStream_t s);
+hipError_t launch_targets64(const DevModel& d, const double* model_host, int min_sep, const int32_t* t10, double* T, hipStream_t s);
 hipError_t launch_import64(const DevModel& d, const float* Xf, const Buffers64& b, hipStream_t s);
 hipError_t launch_export64(const DevModel& d, const Buffers64& b, int parity, float* Xf, float* Vf, float* Pf, hipStream_t s);
 size_t fire_state64_bytes();

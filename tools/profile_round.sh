@@ -18,6 +18,13 @@ cd $R
 python tools/pmc_summarise.py $O/pmc_fetch $O/pmc_write k_cluster --json $O/hbm_traffic_k_cluster.json --n 455 --replicas 20 --steps-per-dispatch 2000 > $O/pmc_hbm_summary.txt
 python tools/pmc_summarise.py $O/pmc_sq k_cluster > $O/pmc_sq_summary.txt
 fi
+cd /tmp
+# the fp64 step kernel (option precision = 64) and config 5's per-step kernel: kernel traces; config 5's SQ counters
+rocprofv3 --kernel-trace --stats -d $O/trace_f64 -o t --output-format csv -- python3 $R/bench.py --dtype f64 --steps 200 --warmup 400 --no-cpu-baseline --no-side-figures > $O/bench_f64_under_rocprof.json 2> $O/trace_f64.log
+if [ "$2" != "traces" ]; then
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_sq_config5 -o p --output-format csv -- python3 $R/tools/config5_profile_run.py 0 > $O/pmc_sq_config5.log 2>&1
+python3 $R/tools/pmc_summarise.py $O/pmc_sq_config5 k_step > $O/pmc_sq_config5_summary.txt
+fi
 cd $R
 python tools/trace_check.py $O/trace_default/t_kernel_stats.csv $O/bench_default_under_rocprof.json $O/trace_s20/t_kernel_stats.csv $O/bench_s20_under_rocprof.json > $O/trace_vs_bench.txt
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
