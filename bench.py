@@ -191,40 +191,17 @@ def side_figures(device, IF, model, fire, stages, args, B):
     return out
 
 
-def config4_block(s, rank, world, dist, device, sync_all, totals, headline_kernel):
-    """All 23 chromosomes at 500 kb x 20 replicas (test.sh:9-12; chr2_500kb is the documented stand-in), matrices to ranks by
-    longest-processing-time-first on their restraint counts, every rank solves its share through the C ABI (full default schedule with the
-    gradient exit, scoring included), ONE gather of the model records, per-chromosome ranking on rank 0: the code of
-    `python -m chromosome3d_amd.batch`, timed barrier to barrier around solve + gather (inputs already parsed: they are resident numpy arrays)."""
-    from chromosome3d_amd import batch, sharding
-    standins = set()
-    mats = batch.load_matrices(os.path.join(ROOT, "tests", "golden", "all45"), "_500kb", standins)
-    costs = batch.job_costs(mats)
-    mine = sharding.lpt_assign(costs, world)[rank]
-    def count(cid, solver):                                # launches of the HEADLINE kernel instantiation belong in process_totals
-        if solver.step_kernel_name == headline_kernel:
-            _, st, la = solver.last_timing()
-            totals["sa_steps"] += st
-            totals["launches"] += la
-    batch.solve_assigned(s, mats, mine[:1], 20, on_job=count)            # first touch of this path (buffers of the largest job), untimed
-    sync_all()
-    t0 = time.perf_counter()
-    rec = batch.solve_assigned(s, mats, mine, 20, on_job=count)
-    t_solve = time.perf_counter() - t0
-    allrec = batch.gather(rec, dist, device)
-    sync_all()
-    wall = time.perf_counter() - t0
-    load = np.array([[float(len(mine)), float(sum(costs[k] for k in mine)), t_solve, float(rec[:, 4].sum()) / 20.0]])
-    loads = batch.gather(load, dist, device)
-    if rank != 0:
-        return None
-    per = batch.rank_per_chromosome(allrec, len(mats))
-    return {"workload": f"{len(mats)} chromosomes at 500 kb x 20 replicas ({len(allrec)} models), LPT over {world} rank(s), one gather",
-            "wall_s": round(wall, 4), "models_per_s": round(len(allrec) / wall, 1), "standins": sorted(standins),
-            "per_rank": [{"chromosomes": int(l[0]), "restraints": int(l[1]), "solve_s": round(float(l[2]), 4), "anneal_device_ms": round(float(l[3]), 2)} for l in loads],
-            "chromosomes_ranked": len(per), "spearman_best_ranked_mean": round(-float(np.mean([r[0, 3] for r in per])), 4),
-            "note": "solve_s = the rank's wall for its chromosomes (K1, 5172-step schedule with gradient exit, read-back, Spearman of 20 models each); "
-                    "wall_s = barrier to barrier incl. the gather; the reference runs this as 23 background processes (test.sh:9-12)"}
+def config4_in_a_child():
+    """One GPU: BASELINE configs[3] through `python -m chromosome3d_amd.batch --bench-block` as a child process of its own (not under
+    whatever profiler watches this one: its chr1_500kb job runs the headline kernel instantiation in launches of another length, and the
+    kernel trace of THIS command must show the timed launches only).  More ranks: in process, batch.bench_block (below)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS")) and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-m", "chromosome3d_amd.batch", "--bench-block"], capture_output=True, text=True, cwd=ROOT, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": (p.stdout + p.stderr)[-300:]}
+    return json.loads(lines[-1])
 
 
 def end_to_end(IF):
@@ -476,7 +453,8 @@ def main():
     # ---- BASELINE configs[3] in every line: all 23 chromosomes at 500 kb x 20 replicas over the ranks (the sharding that scales) ----
     c4 = None
     if not args.no_side_figures and args.dtype == "f32":
-        c4 = config4_block(s, rank, world, dist, "cuda" if on_gpu_group else "cpu", sync_all, totals, kernel)
+        from chromosome3d_amd import batch
+        c4 = config4_in_a_child() if (world == 1 and dist is None) else batch.bench_block(s, rank, world, dist, "cuda" if on_gpu_group else "cpu", sync_all)
 
     if rank == 0:
         value = total_replicas * args.steps / wall
@@ -524,9 +502,9 @@ def main():
             "us_per_step_device": round(us_per_step_dev, 4),
             "us_per_step_kernel": round(kernel_us_region / args.steps, 4),
             "process_totals": {"sa_steps": totals["sa_steps"], "step_kernel_launches": totals["launches"],
-                               "note": "every launch of the headline kernel instantiation in this process (two full anneals, the call pattern three times: "
-                                       "untimed, timed, kernel-stamped; config 4's chr1_500kb job): a kernel trace's TotalDurationNs of that kernel / sa_steps = "
-                                       "us_per_step_kernel"},
+                               "note": "everything this process ran on the headline kernel (two full anneals in calls of --steps, the call pattern three times: "
+                                       "untimed, timed, kernel-stamped; config 4 and the end-to-end run are child processes): a kernel trace's TotalDurationNs of "
+                                       "the step kernel / sa_steps = us_per_step_kernel"},
             "graph_captures_in_timed_regions": int(captures_in_timed),
             "multi_step_launches_abandoned": int(fallbacks_in_timed),
             "wall_s_per_chromosome_full_schedule": round(full_wall, 5),

@@ -114,6 +114,39 @@ def rank_per_chromosome(rec, n_chrom):
     return out
 
 
+def bench_block(s, rank, world, dist, device, sync_all=None, inputs=None):
+    """The `config4` block of a bench.py line: all 23 chromosomes at 500 kb x 20 replicas (test.sh:9-12; chr2_500kb is the documented
+    stand-in), matrices to ranks by longest-processing-time-first on their restraint counts, every rank solves its share through the C
+    ABI (full default schedule with the gradient exit, scoring included), ONE gather of the model records, per-chromosome ranking on rank
+    0 — timed barrier to barrier around solve + gather (the matrices are parsed before: resident numpy arrays).  Returns the dict on rank
+    0, None elsewhere."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sync_all = sync_all or (lambda: None)
+    standins = set()
+    mats = load_matrices(inputs or os.path.join(root, "tests", "golden", "all45"), "_500kb", standins)
+    costs = job_costs(mats)
+    mine = sharding.lpt_assign(costs, world)[rank]
+    solve_assigned(s, mats, mine[:1], 20)                  # first touch of this path (buffers of the largest job), untimed
+    sync_all()
+    t0 = time.perf_counter()
+    rec = solve_assigned(s, mats, mine, 20)
+    t_solve = time.perf_counter() - t0
+    allrec = gather(rec, dist, device)
+    sync_all()
+    wall = time.perf_counter() - t0
+    load = np.array([[float(len(mine)), float(sum(costs[k] for k in mine)), t_solve, float(rec[:, 4].sum()) / 20.0]])
+    loads = gather(load, dist, device)
+    if rank != 0:
+        return None
+    per = rank_per_chromosome(allrec, len(mats))
+    return {"workload": f"{len(mats)} chromosomes at 500 kb x 20 replicas ({len(allrec)} models), LPT over {world} rank(s), one gather",
+            "wall_s": round(wall, 4), "models_per_s": round(len(allrec) / wall, 1), "standins": sorted(standins),
+            "per_rank": [{"chromosomes": int(l[0]), "restraints": int(l[1]), "solve_s": round(float(l[2]), 4), "anneal_device_ms": round(float(l[3]), 2)} for l in loads],
+            "chromosomes_ranked": len(per), "spearman_best_ranked_mean": round(-float(np.mean([r[0, 3] for r in per])), 4),
+            "note": "solve_s = the rank's wall for its chromosomes (K1, 5172-step schedule with gradient exit, read-back, Spearman of 20 models each); "
+                    "wall_s = barrier to barrier incl. the gather; the reference runs this as 23 background processes (test.sh:9-12)"}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -126,6 +159,7 @@ def main(argv=None):
     ap.add_argument("--json", action="store_true", help="one JSON line with the per-chromosome ranking instead of the table")
     ap.add_argument("--gpus", type=int, default=0, help="ranks = GPUs (0: WORLD_SIZE if set, else 1); > 1 without WORLD_SIZE starts them")
     ap.add_argument("--dist", action="store_true", help="initialise the process group even at one rank (RCCL path on a one-GPU box)")
+    ap.add_argument("--bench-block", action="store_true", help="print bench.py's `config4` block (one JSON line) and nothing else")
     args = ap.parse_args(argv)
 
     from . import launch
@@ -133,6 +167,16 @@ def main(argv=None):
     rank, local, world = launch.ensure_ranks(gpus, sys.argv[1:] if argv is None else list(argv), module="chromosome3d_amd.batch",
                                              what="-m chromosome3d_amd.batch")
     dist, device, local = launch.init_process_group(local, world, force=args.dist)
+    if args.bench_block:
+        s = Solver(local)
+        blk = bench_block(s, rank, world, dist, device, (lambda: dist.barrier()) if dist is not None else None, args.inputs)
+        s.close()
+        if rank == 0:
+            print(json.dumps(blk), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     t0 = time.perf_counter()
     standins = set()
     mats = load_matrices(args.inputs, args.pattern, standins)

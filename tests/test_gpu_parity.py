@@ -437,9 +437,11 @@ def test_minimiser_reaches_a_stationary_point_and_energy_drops(solver):
 # ---------------------------------------------------------------------------------------------
 # whole schedule: statistical parity (device vs oracle, and vs the bundled reference model)
 # ---------------------------------------------------------------------------------------------
-# chr13_1mb: its replicas spread over 0.88-0.91 (several folds) and the reference's 0.915 lies above all of them
-# (profiles/r03_parity_sweep_all45.md: best of TWENTY -0.007, rank-matched -0.019); the best of the EIGHT replicas here is -0.035
-@pytest.mark.parametrize("cid,tol_ref", [("chr21_1mb", 0.02), ("chr13_1mb", 0.04), ("chr19_500kb", 0.02)])
+# Best-energy replica of EIGHT against the bundled model: +-0.02 — widened only by what THIS run's own replicas justify: on a chromosome with
+# several folds (chr13_1mb: the eight replicas spread by ~0.014, the twenty of profiles/r04_parity_sweep_all45.md by 0.014 with the best
+# at -0.008) the bound is 2.5 standard deviations of the run's own Spearman values, and the reference's value must lie within that of the
+# replica CLOSEST to it as well.  (The per-matrix +-0.01 acceptance with twenty replicas is tests/test_gpu_northstar.py.)
+@pytest.mark.parametrize("cid,tol_ref", [("chr21_1mb", 0.02), ("chr13_1mb", 0.02), ("chr19_500kb", 0.02)])
 def test_full_schedule_statistics(solver, O, cid, tol_ref):
     from chromosome3d_amd import default_fire, default_model, default_schedule, pipeline
     IF = load_if(cid)
@@ -461,7 +463,9 @@ def test_full_schedule_statistics(solver, O, cid, tol_ref):
     assert abs(rho.mean() - np.mean(rho_o)) < 0.01, (rho, rho_o)
     assert abs(np.median(en[:, 0]) / np.median(e_o) - 1.0) < 0.03, (en[:, 0], e_o)
     # against the bundled reference model: Spearman of the best-ranked replica
-    assert abs(rho[best] - REF_SPEARMAN[cid]) < tol_ref, (rho[best], REF_SPEARMAN[cid])
+    tol = max(tol_ref, 2.5 * float(rho.std()))
+    assert abs(rho[best] - REF_SPEARMAN[cid]) < tol, (rho[best], REF_SPEARMAN[cid], float(rho.std()))
+    assert np.abs(rho - REF_SPEARMAN[cid]).min() < 0.02, (rho, REF_SPEARMAN[cid])
     order = s.rank()
     assert order[0] == best or int(en[order[0], 0]) == int(en[best, 0])
 

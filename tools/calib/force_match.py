@@ -10,7 +10,10 @@ residual force.  Host only (numpy); no GPU, no oracle in the product.
     python tools/calib/force_match.py shape     # g(delta) recovered point by point, lower side pinned to 2 S delta
     python tools/calib/force_match.py grid      # residual over (rswitch, asymptote) x (lower side: square / soft)
     python tools/calib/force_match.py chain     # bond and (i,i+2) tension against distance under the best NOE form
-Committed output: profiles/r03_force_matching.txt.  What it says (both resolutions separately, same answer):
+    python tools/calib/force_match.py classes   # round 4: g(delta) recovered separately per TARGET class (the lower side of far targets decays)
+    python tools/calib/force_match.py lower     # round 4: residual of parametric lower-side families (clamp / soft with exponent 1 / 2)
+Committed output: profiles/r03_force_matching.txt, profiles/r04_force_matching_lower_side.txt.  Round 4 takes no PARAMETER from here any more
+(this sees all 45 models; tools/calib/relax_fit.py trains on the 1 Mb half only): it is the diagnostic that names functional forms.  What it says (both resolutions separately, same answer):
 the upper tail of the soft-square is HALF of what round 2 used (switch at 0.5 A, slope 2 S 0.5 = 10, i.e. CNS
 `rswitch 0.5, asymptote 1.0` rather than `1.0 / 2.0`), the lower side is square up to 7-11 A and saturates beyond,
 pseudo-bond stiffness ~300 kcal/mol/A^2 around 3.95 A, (i,i+2) ~45 around 6.1 A, and the repel term is steeper and
@@ -194,8 +197,70 @@ def mode_chain():
         print(f"  (i,i+2) linear fit over 3..9 A: k = {-k / 2:.1f}, a0 = {-c / k:.3f}")
 
 
+def mode_classes():
+    """g(delta) as a free piecewise-linear function PER TARGET CLASS (the scale is pinned on the 12-20 A class, lower side [-3, 0])."""
+    models = prepare(None)
+    for m in models:
+        m.t = targets(load(m.cid))[m.ii, m.jj]
+    grid = np.array([-40, -25, -16, -11, -8, -5, -3, -1.5, 0, 0.5, 1, 2, 4, 8, 16, 30], float); K = len(grid)
+    classes = [(0, 12), (12, 20), (20, 30), (30, 999)]
+    rows = []
+    for m in models:
+        blocks = []
+        for (lo, hi) in classes:
+            sel = (m.t >= lo) & (m.t < hi)
+            G = np.zeros((3 * m.n, K))
+            if sel.any():
+                a0, w0, a1, w1 = hat(m.dl[sel], grid); ii = m.ii[sel]; jj = m.jj[sel]; u = m.u[sel]
+                for (a, w) in ((a0, w0), (a1, w1)):
+                    f = -(w[:, None]) * u
+                    for c in range(3):
+                        np.add.at(G, (3 * ii + c, a), f[:, c]); np.add.at(G, (3 * jj + c, a), -f[:, c])
+            blocks.append(G - m.Q @ (m.Q.T @ G))
+        rows.append(np.hstack(blocks + [m.Rp]))
+    A = np.vstack(rows)
+    pin = [K + k for k in range(K) if -3 <= grid[k] <= 0]
+    b = -(A[:, pin] * (2 * S_NOE * grid[[q - K for q in pin]])[None, :]).sum(1)
+    keep = [k for k in range(A.shape[1]) if k not in pin]
+    sol, *_ = np.linalg.lstsq(A[:, keep], b, rcond=None)
+    full = np.zeros(A.shape[1]); full[pin] = 2 * S_NOE * grid[[q - K for q in pin]]; full[keep] = sol
+    print(f"\n== g(delta) per target class, 45 models; scale pinned on the 12-20 A class, [-3, 0]; residual {np.linalg.norm(A @ full) / np.linalg.norm(b):.3f};  value (column weight)")
+    print("   delta   " + "  ".join(f"t in [{lo},{hi})".rjust(16) for lo, hi in classes))
+    for k in range(K):
+        print(f"  {grid[k]:6.1f}   " + "  ".join(f"{full[c * K + k]:9.1f} ({np.linalg.norm(A[:, c * K + k]):5.0f})" for c in range(len(classes))))
+    print("   the far class (targets > 30 A) rises to a maximum 8-11 A inside the target and falls beyond: -87 (-11), -27 (-16), -9 (-25), -6 (-40);")
+    print("   a soft form with switch 10 A, no asymptote and exponent 2 gives 100 x (10 / D)^3 = 75, 24, 6, 1.6 there; exponent 1: 83, 39, 16, 6")
+
+
+def mode_lower():
+    models = prepare(None)
+    m1 = [m for m in models if m.cid.endswith("_1mb")]; m5 = [m for m in models if m.cid.endswith("_500kb")]
+
+    def soft2(rs, c, mrs, mc, mexp):
+        b = (c - 2 * rs) * rs * rs
+
+        def g(dl):
+            out = 2 * S_NOE * dl; up = dl > rs; out[up] = S_NOE * (c - b / dl[up] ** 2)
+            lo = dl < -mrs; D = -dl[lo]
+            if mexp == 1:
+                out[lo] = -S_NOE * (mc - (mc - 2 * mrs) * mrs * mrs / D ** 2)
+            else:
+                out[lo] = -S_NOE * (mc - (mc - 2 * mrs) * mrs ** 3 / D ** 3)
+            return out
+        return g
+    print("\n== lower side of the NOE term, upper side fixed at rswitch 0.5 / slope 1.0 x S: residual |F| / |F_noe|, all | 1 Mb | 500 kb")
+    for label, g in ([(f"clamp at {m:g} A (slope 2 S {m:g})", soft(0.5, 1.0, m, 2.0 * m)) for m in (4.0, 5.0, 7.0, 10.0)] +
+                     [(f"soft, exponent 1, mrswitch {m:g}, no asymptote", soft2(0.5, 1.0, m, 0.0, 1)) for m in (6.0, 8.0, 10.0, 12.0)] +
+                     [(f"soft, exponent 2, mrswitch {m:g}, no asymptote", soft2(0.5, 1.0, m, 0.0, 2)) for m in (6.0, 8.0, 10.0, 12.0, 14.0)]):
+        print(f"  {label:52s} " + " ".join(f"{residual(ms, g)[0]:.4f}" for ms in (models, m1, m5)), flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if mode == "classes":
+        mode_classes()
+    if mode == "lower":
+        mode_lower()
     if mode in ("shape", "all"):
         mode_shape()
     if mode in ("grid", "all"):
