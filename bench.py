@@ -143,12 +143,12 @@ def side_figures(device, IF, model, fire, stages, args, B):
     out = {}
     s = Solver(device)
     try:
-        # ---- fp64 leg: same workload, same schedule position (W warm-up steps, then K steps), median of 5 regions ----
+        # ---- fp64 leg: same workload, same schedule position (W warm-up steps, then 200 steps), median of 5 regions ----
         s.set_option("precision", 64)
         s.set_model(model)
         pipeline.IF2dist_new(s, IF)
         s.set_schedule(stages, fire, 0.0, 250)
-        K = min(args.steps, 200)
+        K = 200                                   # the leg's own region length, whatever --steps says (a 20-step region of the per-step path is a third launch-and-join overhead)
         regs = []
         for rep in range(5):
             s.init_replicas(REPLICAS, 82364, 0)

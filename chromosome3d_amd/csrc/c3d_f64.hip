@@ -30,6 +30,8 @@ struct Model64 {
     int n, np, ntiles, min_sep, noe_pot, rep_sep, ang_mode, mexp;      // noe_pot as DevModel's (4 = the fast soft lower side)
     double s_noe, rs, tail_c, tail_b, mrs, mtail_c, mtail_b;
     double k_bond, b0, k_ang, a0, r0_rep, k_rep, mass, fbeta;
+    double nmrs4;                                  // -mrs^4 (the fast soft lower side's bound is nmrs4 / D^3)
+    double t_fac, inv_n;                           // T = t_fac * sum v^2; 1 / n
 };
 struct Step64 {
     int kind;
@@ -92,15 +94,35 @@ __device__ __forceinline__ double reduce_rows64(double a0, double a1, int lane) 
 // d = sqrt(r2) and h = 1 / (2 d) together: v_rsq_f64 (2^29 ulp: 23 bits) + two coupled Newton steps (Goldschmidt form);
 // the results are within an ulp or two of the correctly rounded values (r2 >= 1e-12: no denormal, no zero)
 __device__ __forceinline__ void sqrt_hrsqrt64(double r2, double& d, double& h) {
-    const double y = (double)__builtin_amdgcn_rsqf((float)r2);      // 23-bit seed from the fp32 unit (v_rsq_f64 is no better and slower); 1e-12 <= r2 <= 1e9
-    double g = r2 * y;
-    h = 0.5 * y;
+    // 23-bit seeds from the fp32 unit (v_rsq_f64 is no better and no faster), the halving done there too; 1e-30 <= r2 <= 1e9
+    const float yf = __builtin_amdgcn_rsqf((float)r2);
+    double g = r2 * (double)yf;
+    h = (double)(0.5f * yf);
     double r = fma(-g, h, 0.5);
 #ifdef C3D_F64_TWO_NEWTON
     g = fma(g, r, g); h = fma(h, r, h);
     r = fma(-g, h, 0.5);
 #endif
     d = fma(g, r, g); h = fma(h, r, h);
+}
+
+// 1 / x and sqrt(x) to a rounding or two (fp32 seed, two Newton steps each): the per-workgroup scalars; x > 0 (sqrt64: 0 allowed)
+__device__ __forceinline__ double rcp64(double x) {
+    double y = (double)__builtin_amdgcn_rcpf((float)x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ __forceinline__ double sqrt64(double x) {
+    if (!(x > 0.0)) return 0.0;
+    const double y = (double)__builtin_amdgcn_rsqf((float)x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    return fma(fma(-g, g, x), h, g);                // one more correction of g alone
 }
 
 // HALF of dE/dDelta of the NOE term without S and w.  GEN = tails with a 1/D^2 part.
@@ -121,8 +143,7 @@ __device__ __forceinline__ double half_noe_grad64(const Model64& m, double delta
             e = fma(-D, y, 1.0);
             y = fma(y, e, y);
 #endif
-            const double q = m.mrs * y;
-            return fmin(fmax(delta, -m.mrs * (q * q * q)), m.rs);
+            return fmin(fmax(delta, (y * y) * (y * m.nmrs4)), m.rs);       // nmrs4 = -mrs^4
         }
         else return delta;
     } else {
@@ -145,7 +166,9 @@ template <int POT, bool GEN>
 __device__ __forceinline__ void pair64(const Model64& m, double nws4, double wr4, double R2, double T, double xi, double yi, double zi,
                                        double xj, double yj, double zj, double& fx, double& fy, double& fz) {
     const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
-    const double r2 = fmax(fma(dx, dx, fma(dy, dy, dz * dz)), 1e-12);
+    // The guard against r2 = 0 (the self term; the CPU restatement clamps at 1e-12, which no pair of distinct beads ever reaches) rides in the
+    // fma chain: 1e-30 is below half an ulp of any r2 > 1e-14, so every real pair keeps its bits, and the self term stays finite (x 0 = 0).
+    const double r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, 1e-30)));
     double d, h;
     sqrt_hrsqrt64(r2, d, h);
     double wn = nws4;
@@ -194,6 +217,20 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
     const size_t roff = (size_t)rep * 3 * np;
     // ---- stage the replica's coordinates; the previous step's sums meanwhile ----
     for (int b = 2 * tid; b < 3 * np; b += 2 * kBlock64) *reinterpret_cast<double2*>(sm64 + b) = *reinterpret_cast<const double2*>(xin + roff + b);
+    // ---- loads whose latency would otherwise be exposed later leave now: the first targets of this wave's rows, the velocities of the two
+    //      rows it finishes ----
+    const int row0 = tile * kTileRows + wave * kRows64;
+    const int ra = min(row0, n - 1), rb = min(row0 + 1, n - 1);
+    const double* Ta = T + (size_t)ra * np + lane;
+    const double* Tb = T + (size_t)rb * np + lane;
+    double ta0 = Ta[0], ta1 = Ta[64], tb0 = Tb[0], tb1 = Tb[64];        // np >= 128: in bounds whatever n is
+    const int row = row0 + lane;
+    double v0x = 0, v0y = 0, v0z = 0;
+    if (lane < kRows64 && row < n && p.kind != 3) {
+        const double* vsrc = p.kind == 4 ? vinit : vin;
+        const size_t ix = roff + row;
+        v0x = vsrc[ix]; v0y = vsrc[ix + np]; v0z = vsrc[ix + 2 * np];
+    }
     // ---- the replica's scalars of this step: ONE wave forms them (the sums of 57 tiles through four butterflies, six fp64 divisions and
     //      a square root are ~400 instruction slots — as much as two thirds of a wave's pair loop) and leaves them in LDS before the
     //      barrier everybody waits at anyway ----
@@ -208,19 +245,22 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
             for (int t = lane; t < m.ntiles; t += 64) { s0 += pp[4 * t]; s1 += pp[4 * t + 1]; s2 += pp[4 * t + 2]; s3 += pp[4 * t + 3]; }
             s0 = wave_sum64(s0); s1 = wave_sum64(s1); s2 = wave_sum64(s2); s3 = wave_sum64(s3);
         }
+        // (reciprocals and square roots by seed + two Newton steps, the constant factors folded on the host: the correctly rounded
+        //  divisions and sqrt of the straightforward form are ~230 dependent fp64 operations — a microsecond on every workgroup's
+        //  critical path, more than the launch boundary hides; these are a rounding or two away from them)
         double lam = 1.0, cm0 = 0, cm1 = 0, cm2 = 0, keep = 0.0, mix = 0.0;
         if (p.kind == 0 || p.kind == 1) {
-            const int ndf = 3 * n - 3;
-            double tprev = m.mass * s0 / kAccel64 / ((ndf > 0 ? ndf : 1) * kBoltz64);
+            double tprev = m.t_fac * s0;                // mass / kAccel / (ndf kBoltz) * sum v^2
             if (tprev < 1e-2) tprev = 1e-2;
-            if (p.kind == 0) { double l2 = 1.0 + p.dt * m.fbeta * (p.t_bath / tprev - 1.0); if (l2 < 0) l2 = 0; lam = sqrt(l2); }
-            else lam = sqrt(p.t_bath / tprev);
-            cm0 = s1 / n; cm1 = s2 / n; cm2 = s3 / n;
+            const double ratio = p.t_bath * rcp64(tprev);
+            if (p.kind == 0) { double l2 = 1.0 + p.dt * m.fbeta * (ratio - 1.0); if (l2 < 0) l2 = 0; lam = sqrt64(l2); }
+            else lam = sqrt64(ratio);
+            cm0 = s1 * m.inv_n; cm1 = s2 * m.inv_n; cm2 = s3 * m.inv_n;
         } else if (p.kind == 2 || p.kind == 3) {
             if (p.kind == 2) st = sin[rep];
             if (s0 > 0) {                               // power of the previous evaluation positive (kind 3: sums are 0)
                 keep = 1.0 - st.alpha;
-                mix = st.alpha * sqrt(s2 / (s1 > 1e-30 ? s1 : 1e-30));
+                mix = st.alpha * sqrt64(s2 * rcp64(s1 > 1e-30 ? s1 : 1e-30));
                 if (st.npos > fp.n_min) { st.dt = st.dt * fp.f_inc < fp.dt_max ? st.dt * fp.f_inc : fp.dt_max; st.alpha *= fp.f_alpha; }
                 st.npos += 1;
             } else {
@@ -233,28 +273,54 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
     __syncthreads();
 
     // ---- pair forces of this wave's two rows ----
-    const int row0 = tile * kTileRows + wave * kRows64;
-    const int ra = min(row0, n - 1), rb = min(row0 + 1, n - 1);
     double fxa = 0, fya = 0, fza = 0, fxb = 0, fyb = 0, fzb = 0;
     const double R2 = (p.repel_s * m.r0_rep) * (p.repel_s * m.r0_rep);
     const double wr4 = p.w_vdw * m.k_rep * 4.0;
     if (p.kind != 4) {
         const double xa = xs[ra], ya = ys[ra], za = zs[ra], xb = xs[rb], yb = ys[rb], zb = zs[rb];
         const double nws4 = -4.0 * p.w_all * m.s_noe;
-        const double* Ta = T + (size_t)ra * np + lane;
-        const double* Tb = T + (size_t)rb * np + lane;
-        // the targets of the next two columns are in flight while these two compute
-        double ta0 = Ta[0], ta1 = Ta[64], tb0 = Tb[0], tb1 = Tb[64];
-        for (int j = lane; j < np; j += 128) {
-            const int jn = j + 128 < np ? 128 : 0;          // the last pass re-reads itself (in bounds)
-            Ta += jn; Tb += jn;
-            const double na0 = Ta[0], na1 = Ta[64], nb0 = Tb[0], nb1 = Tb[64];
-            const double x0 = xs[j], y0 = ys[j], z0 = zs[j], x1 = xs[j + 64], y1 = ys[j + 64], z1 = zs[j + 64];
-            pair64<POT, GEN>(m, nws4, wr4, R2, ta0, xa, ya, za, x0, y0, z0, fxa, fya, fza);
-            pair64<POT, GEN>(m, nws4, wr4, R2, tb0, xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
-            pair64<POT, GEN>(m, nws4, wr4, R2, ta1, xa, ya, za, x1, y1, z1, fxa, fya, fza);
-            pair64<POT, GEN>(m, nws4, wr4, R2, tb1, xb, yb, zb, x1, y1, z1, fxb, fyb, fzb);
-            ta0 = na0; ta1 = na1; tb0 = nb0; tb1 = nb1;
+        // Columns: two per lane and pass (j, j + 64) over the first n & ~127 of them, the next two in flight while these two compute; then
+        // ONE column per lane if 64 or more are left, then the last n % 64 columns — both rows of the wave in one pass where they fit
+        // (lane = (row, column)).  No lane evaluates a padding column pair by pair any more (455 beads: 15 pair terms per lane, not 16);
+        // a lane without a column takes the padding bead n (1e4 A away, no target: an exact zero).
+        const int nmain = n & ~127;
+        if (nmain > 0) {
+            for (int j = lane; j < nmain; j += 128) {
+                const int jn = j + 128 < nmain ? 128 : 0;       // the last pass re-reads itself (in bounds)
+                Ta += jn; Tb += jn;
+                const double na0 = Ta[0], na1 = Ta[64], nb0 = Tb[0], nb1 = Tb[64];
+                const double x0 = xs[j], y0 = ys[j], z0 = zs[j], x1 = xs[j + 64], y1 = ys[j + 64], z1 = zs[j + 64];
+                pair64<POT, GEN>(m, nws4, wr4, R2, ta0, xa, ya, za, x0, y0, z0, fxa, fya, fza);
+                pair64<POT, GEN>(m, nws4, wr4, R2, tb0, xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
+                pair64<POT, GEN>(m, nws4, wr4, R2, ta1, xa, ya, za, x1, y1, z1, fxa, fya, fza);
+                pair64<POT, GEN>(m, nws4, wr4, R2, tb1, xb, yb, zb, x1, y1, z1, fxb, fyb, fzb);
+                ta0 = na0; ta1 = na1; tb0 = nb0; tb1 = nb1;
+            }
+        }
+        const double* Tra = T + (size_t)ra * np;
+        const double* Trb = T + (size_t)rb * np;
+        int c0 = nmain;
+        if (n - c0 >= 64) {
+            const int j = c0 + lane;
+            const double x0 = xs[j], y0 = ys[j], z0 = zs[j];
+            pair64<POT, GEN>(m, nws4, wr4, R2, Tra[j], xa, ya, za, x0, y0, z0, fxa, fya, fza);
+            pair64<POT, GEN>(m, nws4, wr4, R2, Trb[j], xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
+            c0 += 64;
+        }
+        const int left = n - c0;                             // 0 .. 63 columns
+        if (left > 0 && 2 * left <= 64) {
+            const bool second = lane >= left;                // lanes [0, left): row a; [left, 2 left): row b; beyond: the padding bead
+            const int c = lane - (second ? left : 0);
+            const int j = c < left ? c0 + c : n;
+            const double xr = second ? xb : xa, yr = second ? yb : ya, zr = second ? zb : za;
+            double tx = 0, ty = 0, tz = 0;
+            pair64<POT, GEN>(m, nws4, wr4, R2, (second ? Trb : Tra)[j], xr, yr, zr, xs[j], ys[j], zs[j], tx, ty, tz);
+            if (second) { fxb += tx; fyb += ty; fzb += tz; } else { fxa += tx; fya += ty; fza += tz; }
+        } else if (left > 0) {
+            const int j = lane < left ? c0 + lane : n;
+            const double x0 = xs[j], y0 = ys[j], z0 = zs[j];
+            pair64<POT, GEN>(m, nws4, wr4, R2, Tra[j], xa, ya, za, x0, y0, z0, fxa, fya, fza);
+            pair64<POT, GEN>(m, nws4, wr4, R2, Trb[j], xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
         }
     }
     double Fx = reduce_rows64(fxa, fxb, lane), Fy = reduce_rows64(fya, fyb, lane), Fz = reduce_rows64(fza, fzb, lane);
@@ -272,13 +338,9 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
     // ---- lanes 0, 1 finish one row each (the CPU restatement's update, c3o_md_step / c3o_fire_step) ----
     const double lam = scal[0], cm0 = scal[1], cm1 = scal[2], cm2 = scal[3], keep = scal[4], mix = scal[5];
     st.dt = scal[6];
-    const int row = row0 + lane;
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     if (lane < kRows64 && row < n) {
         const size_t ix = roff + row, iy = ix + np, iz = iy + np;
-        double v0x = 0, v0y = 0, v0z = 0;
-        if (p.kind == 4) { v0x = vinit[ix]; v0y = vinit[iy]; v0z = vinit[iz]; }
-        else if (p.kind != 3) { v0x = vin[ix]; v0y = vin[iy]; v0z = vin[iz]; }
         const double x0 = xs[row], y0 = ys[row], z0 = zs[row];
         double vx, vy, vz, xn, yn, zn;
         if (p.kind == 4) {                              // MD begin: Maxwell velocities, no move
@@ -296,7 +358,8 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
             vx += acc * Fx; vy += acc * Fy; vz += acc * Fz;
             const double dxs = st.dt * vx, dys = st.dt * vy, dzs = st.dt * vz;
             const double d2 = dxs * dxs + dys * dys + dzs * dzs;
-            const double scl = d2 > fp.max_step * fp.max_step ? fp.max_step / sqrt(d2) : 1.0;
+            double scl = 1.0;
+            if (d2 > fp.max_step * fp.max_step) { double dd, hh; sqrt_hrsqrt64(d2, dd, hh); hh = fma(fma(-dd, hh, 0.5), hh, hh); scl = fp.max_step * (hh + hh); }
             xn = x0 + scl * dxs; yn = y0 + scl * dys; zn = z0 + scl * dzs;
         }
         xout[ix] = xn; xout[iy] = yn; xout[iz] = zn;
@@ -361,8 +424,10 @@ static Model64 model64(const DevModel& d, const double* host) {
     m.tail_c = host[2] * host[1]; m.tail_b = (m.tail_c - 2.0 * m.rs) * m.rs * m.rs;
     // lower side beyond mrs: dE/dD = mtail_c - mtail_b / D^(mexp + 1)
     m.mrs = host[4]; m.mtail_c = host[3]; m.mtail_b = (m.mtail_c - 2.0 * m.mrs) * m.mrs * m.mrs * (m.mexp == 2 ? m.mrs : 1.0);
+    m.nmrs4 = -(m.mrs * m.mrs) * (m.mrs * m.mrs);
     if (m.noe_pot == 4 && !(m.mexp == 2 && m.mtail_c == 0.0 && m.tail_b == 0.0 && m.tail_c == 2.0 * m.rs)) m.noe_pot = 3;   // (cannot happen: same test in doubles)
     m.k_bond = host[5]; m.b0 = host[6]; m.k_ang = host[7]; m.a0 = host[8]; m.r0_rep = host[9]; m.k_rep = host[10]; m.mass = host[11]; m.fbeta = host[12];
+    { const int ndf = 3 * d.n - 3; m.t_fac = m.mass / kAccel64 / ((ndf > 0 ? ndf : 1) * kBoltz64); m.inv_n = 1.0 / d.n; }
     return m;
 }
 static bool general64(const Model64& m) {
