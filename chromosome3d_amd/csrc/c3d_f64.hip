@@ -237,6 +237,7 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
     double* scal = rowq + 4 * kTileRows;                // [8] lam, cm0, cm1, cm2, keep, mix, dt, (unused)
     FireState64 st;
     st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0;
+    if (wave == 0 && p.kind == 2) st = sin[rep];        // (asked for here, used after the sums have arrived)
     if (wave == 0) {
         const bool needs = p.kind == 0 || p.kind == 1 || p.kind == 2;
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -257,7 +258,6 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
             else lam = sqrt64(ratio);
             cm0 = s1 * m.inv_n; cm1 = s2 * m.inv_n; cm2 = s3 * m.inv_n;
         } else if (p.kind == 2 || p.kind == 3) {
-            if (p.kind == 2) st = sin[rep];
             if (s0 > 0) {                               // power of the previous evaluation positive (kind 3: sums are 0)
                 keep = 1.0 - st.alpha;
                 mix = st.alpha * sqrt64(s2 * rcp64(s1 > 1e-30 ? s1 : 1e-30));
