@@ -35,6 +35,47 @@ def test_force_is_minus_gradient(small, pot):
         assert abs(F[i, c] + g) < 1e-4 * max(1.0, abs(g))
 
 
+@pytest.mark.parametrize("kw", [dict(mrswitch=10.0, masym=0.0, msoexp=2), dict(mrswitch=10.0, masym=0.0, msoexp=1), dict(mrswitch=4.0, masym=8.0, msoexp=1),
+                                dict(mrswitch=6.0, masym=1.5, msoexp=2)])
+def test_lower_side_forms_force_is_minus_gradient_and_continuous(small, kw):
+    """noe_pot 3, the shipped lower side (square up to mrswitch, then the CNS soft form a + b / D^msoexp + masym D) and its relatives: the
+    force is minus the gradient on a coil collapsed far inside its targets (hundreds of pairs beyond mrswitch), an independent numpy
+    restatement of the NOE energy gives the same number, and energy and force are continuous at D = mrswitch."""
+    IF, d10 = small
+    n = len(IF)
+    m = O.default_model(n, noe_pot=3, rswitch=0.5, asym=2.0, k_bond=500.0, k_ang=15.0, a0=5.55, ang_mode=1, r0_rep=5.25, k_rep=4.0, **kw)
+    x = random_coil(n, 11).astype(np.float64) * (0.25 if kw["mrswitch"] >= 10 else 0.7)
+    t = d10 / 10.0
+    i, j = np.triu_indices(n, 5)
+    ok = t[i, j] > 0
+    D = t[i, j][ok] - np.linalg.norm(x[i] - x[j], axis=1)[ok]
+    assert (D > kw["mrswitch"]).sum() > 50 and (D < kw["mrswitch"]).sum() > 20
+    F, e = O.energy_force(m, d10, x, 1.0, 1.0, 0.85)
+    # numpy restatement of the NOE energy alone (S = 10)
+    mrs, mc, p = kw["mrswitch"], kw["masym"], kw["msoexp"]
+    mb = (mc - 2 * mrs) * mrs ** (p + 1) / p
+    ma = mrs * mrs - mb / mrs ** p - mc * mrs
+    dl = -D
+    en = np.where(dl > 0.5, 1.0 * dl - 0.25, dl * dl)                       # upper side: rswitch 0.5, slope 1.0: a = rs^2 - c rs = -0.25
+    en = np.where(D > mrs, ma + mb / np.maximum(D, 1e-9) ** p + mc * D, en)
+    assert abs(10.0 * en.sum() - e[0]) < 1e-8 * abs(e[0])
+
+    def etot(xx):
+        _, ee = O.energy_force(m, d10, xx, 1.0, 1.0, 0.85)
+        return ee[0] + ee[1] + ee[2]
+    rng = np.random.default_rng(1)
+    for _ in range(12):
+        a, c = rng.integers(n), rng.integers(3)
+        h = 1e-5
+        xp, xm = x.copy(), x.copy()
+        xp[a, c] += h
+        xm[a, c] -= h
+        g = (etot(xp) - etot(xm)) / (2 * h)
+        assert abs(F[a, c] + g) < 1e-4 * max(1.0, abs(g))
+    # continuity at the switch: the soft form's value and slope equal the square's
+    assert abs(ma + mb / mrs ** p + mc * mrs - mrs * mrs) < 1e-9 and abs(mc - p * mb / mrs ** (p + 1) - 2 * mrs) < 1e-9
+
+
 def test_net_force_and_torque_vanish(small):
     IF, d10 = small
     n = len(IF)
