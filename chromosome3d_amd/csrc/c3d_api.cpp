@@ -220,7 +220,12 @@ c3d::DevModel dev_model(const c3d_ctx* c) {
     m.inv_rs = 1.0f / h.rswitch; m.nm_rs = -h.mrswitch / h.rswitch;
     // the shipped lower side (square up to mrswitch, then soft with exponent 2 and no asymptote) has a fast form of its own in
     // the clamp-form kernels: device potential 4 (pair_term); it needs the upper tail in clamp form too (slope 2 rswitch)
-    if (h.noe_pot == 3 && h.msoexp == 2 && h.masym == 0.0f && m.tail_b == 0.0f && m.tail_c == 2.0f * m.rs) m.noe_pot = 4;
+    if (h.noe_pot == 3 && h.msoexp == 2 && h.masym == 0.0f && m.tail_b == 0.0f && m.tail_c == 2.0f * m.rs) {
+        m.noe_pot = 4;
+        // its pair term works on (d - t) / MRS (pair_term): the per-pair constants are t / mrs and 1 / mrs, the third run constant is
+        // the upper bound rs / mrs, and the factor applied once per row is W mrs (dev_step: clamp_scale)
+        m.inv_rs = 1.0f / h.mrswitch; m.nm_rs = h.rswitch / h.mrswitch;
+    }
     // column layout of the pair loop (c3d_internal.h): lanes of the last 256-column block own wl consecutive columns, up to 8
     // columns behind it are left over; both follow from n alone, so every launch form sums the same terms in the same order
     {
@@ -258,6 +263,8 @@ c3d::DevFire dev_fire(const c3d_ctx* c) {
     f.n_min = c->fire.n_min;
     return f;
 }
+// the length the clamp form divides (d - t) by: rswitch, or mrswitch for device potential 4 (1 / DevModel::inv_rs in either case)
+float clamp_scale(const c3d_ctx* c) { return dev_model(c).noe_pot == 4 ? c->model.mrswitch : c->model.rswitch; }
 c3d::DevStep dev_step(const c3d_ctx* c, int kind, float dt, float w_all, float w_vdw, float repel_s, float t_bath) {
     c3d::DevStep p;
     p.kind = kind; p.dt = dt; p.w_all = w_all;
@@ -269,7 +276,7 @@ c3d::DevStep dev_step(const c3d_ctx* c, int kind, float dt, float w_all, float w
     p.w_rep4r2 = p.w_rep4 * p.rep_r2;
     // clamp form (c3d_step_core.h pair_term): the NOE weight times rswitch is applied once per row, the repel weight rides
     // relative to it.  A stage without restraint weight (w_all = 0) cannot be written that way: general kernels (zero_weight).
-    p.w_rs = p.w_noe2n * c->model.rswitch;
+    p.w_rs = p.w_noe2n * clamp_scale(c);
     p.kq = p.w_rs != 0.0f ? p.w_rep4r2 / p.w_rs : 0.0f;
     p.t_bath = t_bath;
     return p;

@@ -28,7 +28,7 @@ struct DevModel {
     float rs, tail_c, tail_b;      // soft tail: dE/dD = tail_c - tail_b / D^2  (D > rs)
     float mrs, mtail_c, mtail_b;   // noe_pot 3, lower side: dE/dD = mtail_c - mtail_b / D^(mexp + 1)  (D = t - d > mrs)
     float nmrs;                    // -mrs
-    float inv_rs, nm_rs;           // 1 / rs, -mrs / rs: the clamp form works on (d - t) / (rs d), see pair_term
+    float inv_rs, nm_rs;           // 1 / rs, -mrs / rs: the clamp form works on (d - t) / (rs d), see pair_term (device potential 4: 1 / mrs, rs / mrs)
     // Column layout of the pair loop (c3d_step_core.h): blocks of 256 columns, lane l owns 4 consecutive ones — except in the LAST
     // block, where it owns wl (1..4) consecutive ones: column 256 (nb - 1) + wl l + c.  Up to 8 columns beyond the last block
     // (jl0 .. jl0 + nleft - 1 = n - 1) are "left over": their pair terms are evaluated eight to a row in a separate short pass
@@ -51,7 +51,7 @@ struct DevStep {
     float rep_r2;    // (repel_s * r0_rep)^2
     float inv_rep_r2;// 1 / rep_r2
     float w_rep4r2;  // w_rep4 * rep_r2
-    float w_rs;      // w_noe2n * rs: the factor the clamp form leaves out of every pair term and applies once per row
+    float w_rs;      // w_noe2n * rs (device potential 4: w_noe2n * mrs): the factor the clamp form leaves out of every pair term and applies once per row
     float kq;        // w_rep4r2 / w_rs: the repel weight relative to it (w_noe2n != 0; else the general kernels run)
     float t_bath;
 };

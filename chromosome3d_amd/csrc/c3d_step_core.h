@@ -178,24 +178,28 @@ __device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, c
     // repel on EVERY column: padding beads are 1e4 A away (q = 0), the self term has dx = 0, and the
     // |i-j| < rep_sep neighbours are taken back out in the chain-term pass below
     float c;
-    if constexpr (!GEN) {
+    if constexpr (!GEN && POT == 4) {
+        // Lower side square up to D = t - d = mrs, then the CNS soft form with exponent 2 and no asymptote: dE/dD = 2 mrs^4 / D^3.
+        // This potential is written in Delta = d - t itself, divided through by MRS (round 4, second form: 19 instructions; the first
+        // one bounded u = Delta / (rs d) and took 20): v = t / mrs, mw = 1 / mrs per pair (both 0: no restraint), so
+        //   dl = (d - t) / mrs,  -(dE/dd) / (W mrs) = clamp(dl, -1 / |dl|^3, rs / mrs)      (W = -2 w S, applied once per row: w_rs = W mrs)
+        // with CONSTANT upper bound (k.nm_rs holds rs / mrs for this potential) and the lower bound -|w|^3, w = 1 / dl: it lies below dl
+        // while D < mrs and above it beyond; above the target it is negative and never binds.  dl = 0 (no restraint, or d = t): w = inf,
+        // the bound -inf, the term 0.  The division by d rides in the fma that joins the repel term: d = r2 rinv, rcp, two
+        // multiplications for the bound, v_med3_f32, one multiplication for the repel weight.  (Forming the bound only in waves that
+        // hold a pair that deep — a compare and a scalar branch per pair term — was measured slower: 4.70 against 4.46 us per step at
+        // chr1_500kb x 20, profiles/r04_lower_side_forms.txt.)
+        const float dl = fmaf(r2 * rinv, mw, -v);
+        const float w = __builtin_amdgcn_rcpf(fabsf(dl));
+        const float g = __builtin_amdgcn_fmed3f(dl, -((w * w) * w), k.nm_rs);
+        c = fmaf(g, rinv, k.kq * q01);
+    } else if constexpr (!GEN) {
         const float u = fmaf(-v, rinv, mw);            // (d - t) / (rs d); v = t / rs, mw = 1 / rs (both 0: no restraint)
         float s;
         if constexpr (POT == 1) s = fminf(u, rinv);
         else if constexpr (POT == 0) s = __builtin_amdgcn_fmed3f(u, -rinv, rinv);
         else if constexpr (POT == 3) s = __builtin_amdgcn_fmed3f(u, k.nm_rs * rinv, rinv);   // clamp(u, -mrs/(rs d), 1/d): one v_med3_f32
-        else if constexpr (POT == 4) {
-            // lower side square up to D = t - d = mrs, then the CNS soft form with exponent 2 and no asymptote: dE/dD = 2 mrs^4 / D^3.
-            // In the clamp form's variable (D = -rs u d) that is s = -(mrs / rs)^4 rinv^4 / |u|^3: the lower BOUND of the same v_med3 —
-            // it lies below u while D < mrs and above it beyond; above the target it is negative and never binds.  u = 0 (no restraint,
-            // or d = t): rcp = inf, the bound -inf, s = u = 0.  With kr = -(mrs / rs) rinv (POT 3's bound) and z = kr / |u| the bound is
-            // ((kr z) z) |z|: v_rcp_f32 and four multiplications more than POT 3, none of them of the src0 = src1 kind.  (Forming
-            // it only in waves that hold a pair that deep — a compare and a scalar branch per pair term — was measured slower:
-            // 4.70 against 4.46 us per step at chr1_500kb x 20, profiles/r04_lower_side_forms.txt.)
-            const float kr = k.nm_rs * rinv;
-            const float z = kr * __builtin_amdgcn_rcpf(fabsf(u));
-            s = __builtin_amdgcn_fmed3f(u, ((kr * z) * z) * fabsf(z), rinv);
-        }
+        else if constexpr (POT == 4) s = 0.0f;          // (own form above)
         else s = u;
         c = fmaf(k.kq, q01, s);
     } else {
