@@ -220,9 +220,14 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 #endif
     // per-pair constants of the clamp form (c3d_step_core.h: pair_b = target / rswitch in registers, pair_a = 1 / rswitch where
     // a restraint exists in wave-private LDS), the same for every step of the launch
-    float4 tv[RPW][NB];
+    // (device potential 4, the shipped model: row PAIRS per column, the layout of the packed pair term — c3d_step_core.h pair_term2)
+    constexpr bool PK = POT == 4;
+    float4 tv[PK ? 1 : RPW][NB];
+    PairConsts2<PK ? RPW : 1, NB> pc;
     float4* const mw = reinterpret_cast<float4*>(dump + 8) + (size_t)(is_compute ? cwave : 0) * (RPW * NB * 64);
-    {
+    if constexpr (PK) {
+        pair_consts2_build<RPW, NB>(m, traw, is_compute, lane, pc, mw);
+    } else {
         DevStep p0{};
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
@@ -293,7 +298,8 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             // ---- K2: pair terms of RPW rows, butterfly sums, three words per row for H0 ------------------
             if (p.kind != 4) {
                 float Fx, Fy, Fz;
-                tile_pair_sums_reg<POT, RPW, NB, WL, 1>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
+                if constexpr (PK) tile_pair_sums_pk<RPW, NB, WL>(m, p, pc, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
+                else tile_pair_sums_reg<POT, RPW, NB, WL, 1>(m, p, tv, mw, xs, ys, zs, row0, lane, Fx, Fy, Fz);
                 if (lane < RPW) {
                     const int k = cwave * RPW + lane;
                     fbuf[k] = Fx; fbuf[64 + k] = Fy; fbuf[128 + k] = Fz;

@@ -455,6 +455,151 @@ __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevS
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same pair terms two ROWS at a time in the packed fp32 forms (device potential 4, cluster kernel).  gfx950 issues
+// v_pk_add/mul/fma_f32 — two results — in 1.9-2.0 ns per SIMD where the scalar forms take 1.2-1.6 ns each and a square
+// (v_fmac d,a,a: src0 = src1 in one bank) 2.2-2.45 ns (tools/microbench/valu_packed.hip, profiles/r04_valu_packed_microbench.txt):
+// with three compute waves on a SIMD the pair loop is bound by instruction ISSUE, and a packed instruction carries two pair
+// terms through one issue slot.  The pair is (row r, row r + 1) against ONE column: the row-side operands (coordinates,
+// accumulators, per-pair constants) are natural register pairs, the column's coordinate is one half of the (x_j, x_j+1) pair a
+// ds_read_b128 delivers, selected by op_sel.  Every component goes through exactly the operations of pair_term<4, false> in the
+// same order (v_pk_fma_f32 is v_fma_f32 per half; the sums over a row's columns keep their order), so a row's force has the SAME
+// BITS as from the scalar form: the per-step kernel, the forces hook and the left-over columns keep the scalar form, and the
+// bit-identity tests between the launch forms are what checks this code.  16 packed + 6 scalar instructions (v_rsq, v_rcp,
+// v_med3: no packed forms) for two pair terms, against 2 x 19.
+typedef float float2v __attribute__((ext_vector_type(2)));
+struct PairK2 {
+    float2v k0, k1;              // (1e-12, 1 / rep_r2), (kq, rs / mrs): in VGPRs (an SGPR source costs an issue cycle)
+};
+__device__ __forceinline__ PairK2 pair_k2(const DevModel& m, const DevStep& p) {
+    PairK2 k;
+    k.k0 = float2v{1e-12f, p.inv_rep_r2}; k.k1 = float2v{p.kq, m.nm_rs};
+    asm volatile("" : "+v"(k.k0), "+v"(k.k1));
+    return k;
+}
+// v2 = (t / mrs) of (row r, row r + 1) against the column, mw2 = their (1 / mrs or 0); xi2 .. = the two rows' coordinates;
+// xjp .. = the register pair that holds the column's coordinate in its SEL half.  Written as vector arithmetic: the compiler selects
+// the packed instructions and folds every broadcast ({a, a} of one half of a pair) into op_sel itself — and, knowing the
+// instructions, inserts exactly the wait states gfx950 wants (the result of a packed or transcendental instruction read by the next
+// VALU instruction; an asm statement's operands are invisible to its hazard recogniser: a first version with d = r2 rinv written as
+// asm read stale registers).  The one asm statement is the clamp modifier (left to itself the compiler clamps each half with a
+// v_max_f32).  Handing the two chains of a column pair to one hand-zipped block of 44 instructions (no wait state at all, fixed
+// temporaries v96-v127) was measured SLOWER on the same box: 3.92 against 3.82 us per step at chr1_500kb x 20.
+template <int SEL>
+__device__ __forceinline__ void pair_term2(const PairK2& k, float2v v2, float2v mw2, float2v xi2, float2v yi2, float2v zi2, float2v xjp,
+                                           float2v yjp, float2v zjp, float2v& fx2, float2v& fy2, float2v& fz2) {
+    const float xc = SEL ? xjp.y : xjp.x, yc = SEL ? yjp.y : yjp.x, zc = SEL ? zjp.y : zjp.x;
+    const float2v dx = xi2 - float2v{xc, xc}, dy = yi2 - float2v{yc, yc}, dz = zi2 - float2v{zc, zc};
+    float2v r2 = __builtin_elementwise_fma(dz, dz, float2v{k.k0.x, k.k0.x});                       // dz^2 + 1e-12
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    r2 = __builtin_elementwise_fma(dx, dx, r2);
+    const float2v rinv = float2v{__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+    float2v q01;                                                                                   // clamp01(1 - r2 / R2)
+    asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(q01) : "v"(r2), "v"(k.k0));
+    const float2v d = r2 * rinv;
+    const float2v dl = __builtin_elementwise_fma(d, mw2, -v2);
+    const float2v w = float2v{__builtin_amdgcn_rcpf(fabsf(dl.x)), __builtin_amdgcn_rcpf(fabsf(dl.y))};
+    const float2v lo = -((w * w) * w);
+    const float2v g = float2v{__builtin_amdgcn_fmed3f(dl.x, lo.x, k.k1.y), __builtin_amdgcn_fmed3f(dl.y, lo.y, k.k1.y)};
+    const float2v rep = float2v{k.k1.x, k.k1.x} * q01;                                             // kq * q01
+    const float2v c = __builtin_elementwise_fma(g, rinv, rep);
+    fx2 = __builtin_elementwise_fma(c, dx, fx2);
+    fy2 = __builtin_elementwise_fma(c, dy, fy2);
+    fz2 = __builtin_elementwise_fma(c, dz, fz2);
+}
+// the launch-resident pair constants of a compute wave in the layout the packed form wants: row pairs q = 0 .. RPW/2 - 1 hold
+// (row 2q, row 2q + 1) per column, an odd last row stays a float4 per block
+template <int RPW, int NB>
+struct PairConsts2 {
+    float2v p[RPW / 2 > 0 ? RPW / 2 : 1][NB][4];
+    float4 s[NB];
+};
+// LDS layout of the 1 / mrs-or-0 constants: pair q, block jb: two float4 at ((q NB + jb) 2 + h) 64 + lane,
+// h = 0: (a_r.x, a_r+1.x, a_r.y, a_r+1.y), h = 1: (.z, .z, .w, .w); the odd last row: one float4 at ((RPW - 1) NB + jb) 64 + lane
+template <int RPW, int NB>
+__device__ __forceinline__ void pair_consts2_build(const DevModel& m, const float4 (&traw)[RPW][NB], bool store, int lane, PairConsts2<RPW, NB>& pc,
+                                                   float4* mw_lds) {
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+#pragma unroll
+        for (int q = 0; q < RPW / 2; ++q) {
+            const float4 ta = traw[2 * q][jb], tb = traw[2 * q + 1][jb];
+            pc.p[q][jb][0] = float2v{ta.x * m.inv_rs, tb.x * m.inv_rs}; pc.p[q][jb][1] = float2v{ta.y * m.inv_rs, tb.y * m.inv_rs};
+            pc.p[q][jb][2] = float2v{ta.z * m.inv_rs, tb.z * m.inv_rs}; pc.p[q][jb][3] = float2v{ta.w * m.inv_rs, tb.w * m.inv_rs};
+            if (store) {
+                const float on = m.inv_rs;
+                mw_lds[((q * NB + jb) * 2) * 64 + lane] = make_float4(ta.x > 0.0f ? on : 0.0f, tb.x > 0.0f ? on : 0.0f, ta.y > 0.0f ? on : 0.0f, tb.y > 0.0f ? on : 0.0f);
+                mw_lds[((q * NB + jb) * 2 + 1) * 64 + lane] = make_float4(ta.z > 0.0f ? on : 0.0f, tb.z > 0.0f ? on : 0.0f, ta.w > 0.0f ? on : 0.0f, tb.w > 0.0f ? on : 0.0f);
+            }
+        }
+        if constexpr (RPW & 1) {
+            DevStep p0{};
+            pc.s[jb] = pair_b<false>(m, traw[RPW - 1][jb]);
+            if (store) mw_lds[((RPW - 1) * NB + jb) * 64 + lane] = pair_a<false>(m, p0, traw[RPW - 1][jb]);
+        }
+    }
+}
+// tile_pair_sums_reg for device potential 4 in the packed form (same sums, same bits)
+template <int RPW, int NB, int WL>
+__device__ __forceinline__ void tile_pair_sums_pk(const DevModel& m, const DevStep& p, const PairConsts2<RPW, NB>& pc, const float4* mw_lds,
+                                                  const float* xs, const float* ys, const float* zs, int row0, int lane, float& Fx, float& Fy,
+                                                  float& Fz) {
+    constexpr int NQ = RPW / 2;
+    float2v fx2[NQ > 0 ? NQ : 1], fy2[NQ > 0 ? NQ : 1], fz2[NQ > 0 ? NQ : 1], xi2[NQ > 0 ? NQ : 1], yi2[NQ > 0 ? NQ : 1], zi2[NQ > 0 ? NQ : 1];
+    float fxs = 0.0f, fys = 0.0f, fzs = 0.0f, xis = 0.0f, yis = 0.0f, zis = 0.0f;
+    const PairK2 k2 = pair_k2(m, p);
+    PairK k{};
+    if constexpr (RPW & 1) k = pair_k(m, p);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int ra = min(row0 + 2 * q, m.n - 1), rb = min(row0 + 2 * q + 1, m.n - 1);
+        xi2[q] = float2v{xs[ra], xs[rb]}; yi2[q] = float2v{ys[ra], ys[rb]}; zi2[q] = float2v{zs[ra], zs[rb]};
+        fx2[q] = fy2[q] = fz2[q] = float2v{0.0f, 0.0f};
+    }
+    if constexpr (RPW & 1) { const int row = min(row0 + RPW - 1, m.n - 1); xis = xs[row]; yis = ys[row]; zis = zs[row]; }
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+        constexpr int W4 = 4;
+        const int width = jb == NB - 1 ? WL : W4;           // compile-time after unrolling: the last block's lanes own WL columns
+        const int j = 256 * jb + width * lane;
+        float4 xj, yj, zj;
+        if (width == 4) {
+            xj = *reinterpret_cast<const float4*>(xs + j); yj = *reinterpret_cast<const float4*>(ys + j); zj = *reinterpret_cast<const float4*>(zs + j);
+        } else {
+            xj = make_float4(xs[j], width > 1 ? xs[j + 1] : 0.0f, width > 2 ? xs[j + 2] : 0.0f, 0.0f);
+            yj = make_float4(ys[j], width > 1 ? ys[j + 1] : 0.0f, width > 2 ? ys[j + 2] : 0.0f, 0.0f);
+            zj = make_float4(zs[j], width > 1 ? zs[j + 1] : 0.0f, width > 2 ? zs[j + 2] : 0.0f, 0.0f);
+        }
+        const float2v x01 = float2v{xj.x, xj.y}, x23 = float2v{xj.z, xj.w}, y01 = float2v{yj.x, yj.y}, y23 = float2v{yj.z, yj.w};
+        const float2v z01 = float2v{zj.x, zj.y}, z23 = float2v{zj.z, zj.w};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float4 ma = mw_lds[((q * NB + jb) * 2) * 64 + lane];
+            pair_term2<0>(k2, pc.p[q][jb][0], float2v{ma.x, ma.y}, xi2[q], yi2[q], zi2[q], x01, y01, z01, fx2[q], fy2[q], fz2[q]);
+            if (width > 1) pair_term2<1>(k2, pc.p[q][jb][1], float2v{ma.z, ma.w}, xi2[q], yi2[q], zi2[q], x01, y01, z01, fx2[q], fy2[q], fz2[q]);
+            if (width > 2) {
+                const float4 mb = mw_lds[((q * NB + jb) * 2 + 1) * 64 + lane];
+                pair_term2<0>(k2, pc.p[q][jb][2], float2v{mb.x, mb.y}, xi2[q], yi2[q], zi2[q], x23, y23, z23, fx2[q], fy2[q], fz2[q]);
+                if (width > 3) pair_term2<1>(k2, pc.p[q][jb][3], float2v{mb.z, mb.w}, xi2[q], yi2[q], zi2[q], x23, y23, z23, fx2[q], fy2[q], fz2[q]);
+            }
+            asm volatile("" : "+v"(fx2[q]), "+v"(fy2[q]), "+v"(fz2[q]));      // one row pair's block in flight (register budget)
+        }
+        if constexpr (RPW & 1) {
+            const float4 mw = mw_lds[((RPW - 1) * NB + jb) * 64 + lane];
+            if (width == 4) pair_quad<4, false>(m, p, k, pc.s[jb], mw, xis, yis, zis, xj, yj, zj, fxs, fys, fzs);
+            else pair_quad_w<4, false>(m, p, k, width, pc.s[jb], mw, xis, yis, zis, xj, yj, zj, fxs, fys, fzs);
+            asm volatile("" : "+v"(fxs), "+v"(fys), "+v"(fzs));
+        }
+    }
+    float fx[RPW], fy[RPW], fz[RPW];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { fx[2 * q] = fx2[q].x; fx[2 * q + 1] = fx2[q].y; fy[2 * q] = fy2[q].x; fy[2 * q + 1] = fy2[q].y; fz[2 * q] = fz2[q].x; fz[2 * q + 1] = fz2[q].y; }
+    if constexpr (RPW & 1) { fx[RPW - 1] = fxs; fy[RPW - 1] = fys; fz[RPW - 1] = fzs; }
+    Fx = reduce_rows<RPW>(fx, lane);
+    Fy = reduce_rows<RPW>(fy, lane);
+    Fz = reduce_rows<RPW>(fz, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-replica scalars of a step from the previous step's sums, identical in every wave
 // ---------------------------------------------------------------------------------------------
 struct StepScalars {
