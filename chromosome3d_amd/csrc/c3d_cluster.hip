@@ -567,7 +567,7 @@ hipError_t launch_tear16(int num_cus, void* buf, unsigned* stop, unsigned long l
 // Geometry.  A workgroup = CW compute waves x RPW rows (RW = CW * RPW rows, a multiple of 8, at most 64) + 2 or 4 helpers;
 // a replica = P = ceil(n / RW) workgroups; the replicas of the fullest XCD must fit its CUs, one or two workgroups per CU.
 // Among the geometries that fit, the cheapest by an instruction-count model of one step (VALU issue is the limiter):
-//   per SIMD: ceil(CW / 4) compute waves x (RPW rows x NB blocks x 4 columns x 15 + 60) wave-instructions,
+//   per SIMD: ceil(CW / 4) compute waves x (column slots x instructions per slot of RPW rows + 60) wave-instructions,
 //   + H0's serial tail (~200) + the hand-off (~570 instruction-times = 0.8 us) unless P == 1.
 // Tile sums late (H0 fetches them after B1, LATE = true) where the pair loop of a compute wave — rows x column slots — outlasts
 // H0's later scalars; measured on 13 problems, N = 76 .. 455 (profiles/r03_late_tiles_ab.txt).  Shipped potential only: every
@@ -609,7 +609,10 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
         if (wpc == 1) { if (lds < 84 * 1024) lds = 84 * 1024; }    // more than half of a CU's 160 KB: one workgroup per CU
         else if (lds > 78 * 1024 || threads > 512) continue;        // two per CU must fit
         const int wps = (cw * wpc + 3) / 4;       // compute waves per SIMD; a lone wave issues at ~0.6 of the multi-wave rate
-        const double valu = (wps == 1 ? 1.6 : (wps == 2 ? 1.15 : 1.0)) * wps * (rpw * (4 * (nb - 1) + m.wl) * 15.0 + 60.0);
+        // instructions per column slot of a compute wave: 15 per row (clamp forms); device potential 4: 22 per row PAIR in the packed
+        // form (c3d_step_core.h pair_term2), 19 for an odd last row
+        const double per_slot = m.noe_pot == 4 ? (rpw / 2) * 22.0 + (rpw & 1) * 19.0 : rpw * 15.0;
+        const double valu = (wps == 1 ? 1.6 : (wps == 2 ? 1.15 : 1.0)) * wps * ((4 * (nb - 1) + m.wl) * per_slot + 60.0);
         const double serial = 200.0 + (P > 1 ? 570.0 : 0.0);
         // one workgroup per CU: the serial tail of a step follows its pair loop; two per CU: the tails hide behind the
         // other workgroup's loop where there is one

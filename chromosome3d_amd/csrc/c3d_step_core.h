@@ -354,6 +354,58 @@ __device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevSte
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pair terms two ROWS at a time in the packed fp32 forms (device potential 4, cluster kernel).  gfx950 issues
+// v_pk_add/mul/fma_f32 — two results — in 1.9-2.0 ns per SIMD where the scalar forms take 1.2-1.6 ns each and a square
+// (v_fmac d,a,a: src0 = src1 in one bank) 2.2-2.45 ns (tools/microbench/valu_packed.hip, profiles/r04_valu_packed_microbench.txt):
+// with three compute waves on a SIMD the pair loop is bound by instruction ISSUE, and a packed instruction carries two pair
+// terms through one issue slot.  The pair is (row r, row r + 1) against ONE column: the row-side operands (coordinates,
+// accumulators, per-pair constants) are natural register pairs, the column's coordinate is one half of the (x_j, x_j+1) pair a
+// ds_read_b128 delivers, selected by op_sel.  Every component goes through exactly the operations of pair_term<4, false> in the
+// same order (v_pk_fma_f32 is v_fma_f32 per half; the sums over a row's columns keep their order), so a row's force has the SAME
+// BITS as from the scalar form: the per-step kernel, the forces hook and the left-over columns keep the scalar form, and the
+// bit-identity tests between the launch forms are what checks this code.  16 packed + 6 scalar instructions (v_rsq, v_rcp,
+// v_med3: no packed forms) for two pair terms, against 2 x 19.
+typedef float float2v __attribute__((ext_vector_type(2)));
+struct PairK2 {
+    float2v k0, k1;              // (1e-12, 1 / rep_r2), (kq, rs / mrs): in VGPRs (an SGPR source costs an issue cycle)
+};
+__device__ __forceinline__ PairK2 pair_k2(const DevModel& m, const DevStep& p) {
+    PairK2 k;
+    k.k0 = float2v{1e-12f, p.inv_rep_r2}; k.k1 = float2v{p.kq, m.nm_rs};
+    asm volatile("" : "+v"(k.k0), "+v"(k.k1));
+    return k;
+}
+// v2 = (t / mrs) of (row r, row r + 1) against the column, mw2 = their (1 / mrs or 0); xi2 .. = the two rows' coordinates;
+// xjp .. = the register pair that holds the column's coordinate in its SEL half.  Written as vector arithmetic: the compiler selects
+// the packed instructions and folds every broadcast ({a, a} of one half of a pair) into op_sel itself — and, knowing the
+// instructions, inserts exactly the wait states gfx950 wants (the result of a packed or transcendental instruction read by the next
+// VALU instruction; an asm statement's operands are invisible to its hazard recogniser: a first version with d = r2 rinv written as
+// asm read stale registers).  The one asm statement is the clamp modifier (left to itself the compiler clamps each half with a
+// v_max_f32).  Handing the two chains of a column pair to one hand-zipped block of 44 instructions (no wait state at all, fixed
+// temporaries v96-v127) was measured SLOWER on the same box: 3.92 against 3.82 us per step at chr1_500kb x 20.
+template <int SEL>
+__device__ __forceinline__ void pair_term2(const PairK2& k, float2v v2, float2v mw2, float2v xi2, float2v yi2, float2v zi2, float2v xjp,
+                                           float2v yjp, float2v zjp, float2v& fx2, float2v& fy2, float2v& fz2) {
+    const float xc = SEL ? xjp.y : xjp.x, yc = SEL ? yjp.y : yjp.x, zc = SEL ? zjp.y : zjp.x;
+    const float2v dx = xi2 - float2v{xc, xc}, dy = yi2 - float2v{yc, yc}, dz = zi2 - float2v{zc, zc};
+    float2v r2 = __builtin_elementwise_fma(dz, dz, float2v{k.k0.x, k.k0.x});                       // dz^2 + 1e-12
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    r2 = __builtin_elementwise_fma(dx, dx, r2);
+    const float2v rinv = float2v{__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+    float2v q01;                                                                                   // clamp01(1 - r2 / R2)
+    asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(q01) : "v"(r2), "v"(k.k0));
+    const float2v d = r2 * rinv;
+    const float2v dl = __builtin_elementwise_fma(d, mw2, -v2);
+    const float2v w = float2v{__builtin_amdgcn_rcpf(fabsf(dl.x)), __builtin_amdgcn_rcpf(fabsf(dl.y))};
+    const float2v lo = -((w * w) * w);
+    const float2v g = float2v{__builtin_amdgcn_fmed3f(dl.x, lo.x, k.k1.y), __builtin_amdgcn_fmed3f(dl.y, lo.y, k.k1.y)};
+    const float2v rep = float2v{k.k1.x, k.k1.x} * q01;                                             // kq * q01
+    const float2v c = __builtin_elementwise_fma(g, rinv, rep);
+    fx2 = __builtin_elementwise_fma(c, dx, fx2);
+    fy2 = __builtin_elementwise_fma(c, dy, fy2);
+    fz2 = __builtin_elementwise_fma(c, dz, fz2);
+}
 // targets streamed from global memory, one column block ahead (per-step kernel)
 // NC = false: the instantiation for problems whose last block is a full one and that leave no column over (m.wl == 4,
 // m.nleft == 0: every N > 1024 among them) carries none of the narrow-column code — the per-step kernel is launched once per SA
@@ -364,7 +416,6 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
                                             float4 (&tv)[RPW], float& Fx, float& Fy, float& Fz) {
     float fx[RPW], fy[RPW], fz[RPW];
     float xi[RPW], yi[RPW], zi[RPW];
-    const PairK k = pair_k(m, p);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = min(row0 + r, m.n - 1);
@@ -375,6 +426,49 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
     // full blocks: every lane owns four columns; the next block's targets are in flight while this one computes.  With a
     // narrow last block (m.wl < 4) the loop stops one block early and the last block follows with its own column map.
     const int nfull = (!NC || m.wl == 4) ? nblk : nblk - 1;
+    if constexpr (POT == 4 && !GEN && RPW == 2) {
+        // device potential 4, two rows per wave: the wave's two rows are the row pair of the packed pair term (pair_term2: same bits
+        // as the scalar form below, 11 instead of 19 instructions per pair term); the per-pair constants go straight into register pairs
+        const PairK2 k2 = pair_k2(m, p);
+        const float2v xi2 = float2v{xi[0], xi[1]}, yi2 = float2v{yi[0], yi[1]}, zi2 = float2v{zi[0], zi[1]};
+        float2v fx2 = float2v{0.0f, 0.0f}, fy2 = fx2, fz2 = fx2;
+        const float on = m.inv_rs;
+#define C3D_PK_COL(C, SEL, XP, YP, ZP)                                                                                             \
+        pair_term2<SEL>(k2, float2v{tv[0].C * m.inv_rs, tv[1].C * m.inv_rs}, float2v{tv[0].C > 0.0f ? on : 0.0f, tv[1].C > 0.0f ? on : 0.0f}, \
+                        xi2, yi2, zi2, XP, YP, ZP, fx2, fy2, fz2)
+        for (int jb = 0; jb < nfull; ++jb) {
+            float4 tn[RPW];
+            const int jn = jb + 1 < nblk ? jb + 1 : jb;     // the last block re-reads itself (in bounds)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                tn[r] = *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 256 * jn + 4 * lane);
+            const int j = 256 * jb + 4 * lane;
+            const float4 xj = *reinterpret_cast<const float4*>(xs + j);
+            const float4 yj = *reinterpret_cast<const float4*>(ys + j);
+            const float4 zj = *reinterpret_cast<const float4*>(zs + j);
+            const float2v x01 = float2v{xj.x, xj.y}, x23 = float2v{xj.z, xj.w}, y01 = float2v{yj.x, yj.y}, y23 = float2v{yj.z, yj.w};
+            const float2v z01 = float2v{zj.x, zj.y}, z23 = float2v{zj.z, zj.w};
+            C3D_PK_COL(x, 0, x01, y01, z01); C3D_PK_COL(y, 1, x01, y01, z01); C3D_PK_COL(z, 0, x23, y23, z23); C3D_PK_COL(w, 1, x23, y23, z23);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) tv[r] = tn[r];
+        }
+        if (NC && m.wl != 4) {   // the narrow last block: lanes own m.wl (1..3) consecutive columns
+            if (nblk > 1) tile_prefetch<RPW>(m, tgt, row0, lane, nblk - 1, tv);
+            int width;
+            float4 xj, yj, zj;
+            block_coords(m, xs, ys, zs, nblk - 1, lane, width, xj, yj, zj);
+            const float2v x01 = float2v{xj.x, xj.y}, x23 = float2v{xj.z, xj.w}, y01 = float2v{yj.x, yj.y}, y23 = float2v{yj.z, yj.w};
+            const float2v z01 = float2v{zj.x, zj.y}, z23 = float2v{zj.z, zj.w};
+            C3D_PK_COL(x, 0, x01, y01, z01);
+            if (width > 1) C3D_PK_COL(y, 1, x01, y01, z01);
+            if (width > 2) C3D_PK_COL(z, 0, x23, y23, z23);
+        }
+#undef C3D_PK_COL
+        fx[0] = fx2.x; fx[1] = fx2.y; fy[0] = fy2.x; fy[1] = fy2.y; fz[0] = fz2.x; fz[1] = fz2.y;
+        reduce_and_chain<POT, RPW, GEN, NC>(m, p, tgt, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
+        return;
+    }
+    const PairK k = pair_k(m, p);
     for (int jb = 0; jb < nfull; ++jb) {
         float4 tn[RPW];
         const int jn = jb + 1 < nblk ? jb + 1 : jb;     // the last block re-reads itself (in bounds)
@@ -455,57 +549,6 @@ __device__ __forceinline__ void tile_pair_sums_reg(const DevModel& m, const DevS
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same pair terms two ROWS at a time in the packed fp32 forms (device potential 4, cluster kernel).  gfx950 issues
-// v_pk_add/mul/fma_f32 — two results — in 1.9-2.0 ns per SIMD where the scalar forms take 1.2-1.6 ns each and a square
-// (v_fmac d,a,a: src0 = src1 in one bank) 2.2-2.45 ns (tools/microbench/valu_packed.hip, profiles/r04_valu_packed_microbench.txt):
-// with three compute waves on a SIMD the pair loop is bound by instruction ISSUE, and a packed instruction carries two pair
-// terms through one issue slot.  The pair is (row r, row r + 1) against ONE column: the row-side operands (coordinates,
-// accumulators, per-pair constants) are natural register pairs, the column's coordinate is one half of the (x_j, x_j+1) pair a
-// ds_read_b128 delivers, selected by op_sel.  Every component goes through exactly the operations of pair_term<4, false> in the
-// same order (v_pk_fma_f32 is v_fma_f32 per half; the sums over a row's columns keep their order), so a row's force has the SAME
-// BITS as from the scalar form: the per-step kernel, the forces hook and the left-over columns keep the scalar form, and the
-// bit-identity tests between the launch forms are what checks this code.  16 packed + 6 scalar instructions (v_rsq, v_rcp,
-// v_med3: no packed forms) for two pair terms, against 2 x 19.
-typedef float float2v __attribute__((ext_vector_type(2)));
-struct PairK2 {
-    float2v k0, k1;              // (1e-12, 1 / rep_r2), (kq, rs / mrs): in VGPRs (an SGPR source costs an issue cycle)
-};
-__device__ __forceinline__ PairK2 pair_k2(const DevModel& m, const DevStep& p) {
-    PairK2 k;
-    k.k0 = float2v{1e-12f, p.inv_rep_r2}; k.k1 = float2v{p.kq, m.nm_rs};
-    asm volatile("" : "+v"(k.k0), "+v"(k.k1));
-    return k;
-}
-// v2 = (t / mrs) of (row r, row r + 1) against the column, mw2 = their (1 / mrs or 0); xi2 .. = the two rows' coordinates;
-// xjp .. = the register pair that holds the column's coordinate in its SEL half.  Written as vector arithmetic: the compiler selects
-// the packed instructions and folds every broadcast ({a, a} of one half of a pair) into op_sel itself — and, knowing the
-// instructions, inserts exactly the wait states gfx950 wants (the result of a packed or transcendental instruction read by the next
-// VALU instruction; an asm statement's operands are invisible to its hazard recogniser: a first version with d = r2 rinv written as
-// asm read stale registers).  The one asm statement is the clamp modifier (left to itself the compiler clamps each half with a
-// v_max_f32).  Handing the two chains of a column pair to one hand-zipped block of 44 instructions (no wait state at all, fixed
-// temporaries v96-v127) was measured SLOWER on the same box: 3.92 against 3.82 us per step at chr1_500kb x 20.
-template <int SEL>
-__device__ __forceinline__ void pair_term2(const PairK2& k, float2v v2, float2v mw2, float2v xi2, float2v yi2, float2v zi2, float2v xjp,
-                                           float2v yjp, float2v zjp, float2v& fx2, float2v& fy2, float2v& fz2) {
-    const float xc = SEL ? xjp.y : xjp.x, yc = SEL ? yjp.y : yjp.x, zc = SEL ? zjp.y : zjp.x;
-    const float2v dx = xi2 - float2v{xc, xc}, dy = yi2 - float2v{yc, yc}, dz = zi2 - float2v{zc, zc};
-    float2v r2 = __builtin_elementwise_fma(dz, dz, float2v{k.k0.x, k.k0.x});                       // dz^2 + 1e-12
-    r2 = __builtin_elementwise_fma(dy, dy, r2);
-    r2 = __builtin_elementwise_fma(dx, dx, r2);
-    const float2v rinv = float2v{__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
-    float2v q01;                                                                                   // clamp01(1 - r2 / R2)
-    asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(q01) : "v"(r2), "v"(k.k0));
-    const float2v d = r2 * rinv;
-    const float2v dl = __builtin_elementwise_fma(d, mw2, -v2);
-    const float2v w = float2v{__builtin_amdgcn_rcpf(fabsf(dl.x)), __builtin_amdgcn_rcpf(fabsf(dl.y))};
-    const float2v lo = -((w * w) * w);
-    const float2v g = float2v{__builtin_amdgcn_fmed3f(dl.x, lo.x, k.k1.y), __builtin_amdgcn_fmed3f(dl.y, lo.y, k.k1.y)};
-    const float2v rep = float2v{k.k1.x, k.k1.x} * q01;                                             // kq * q01
-    const float2v c = __builtin_elementwise_fma(g, rinv, rep);
-    fx2 = __builtin_elementwise_fma(c, dx, fx2);
-    fy2 = __builtin_elementwise_fma(c, dy, fy2);
-    fz2 = __builtin_elementwise_fma(c, dz, fz2);
-}
 // the launch-resident pair constants of a compute wave in the layout the packed form wants: row pairs q = 0 .. RPW/2 - 1 hold
 // (row 2q, row 2q + 1) per column, an odd last row stays a float4 per block
 template <int RPW, int NB>
