@@ -14,8 +14,8 @@ separately below.  No annealing result enters the fit any more (round 3 fitted t
 Which of our 20 replicas to compare: the bundled model of a chromosome is ONE of the reference's 20, and NOT its energy-best — the file
 names carry ranks 1..10 (chr22_1mb_rank08, chr4_1mb_rank10, ...); spearman_IF_pdb.pl:73-76 prints the models sorted by their Spearman,
 and that is by all appearance how it was picked.  Both readings are asserted:
-  * best-ENERGY replica (the literal north star): 43 of 45 within +-0.01 for every one of 8 seeds (profiles/r04_seed_robustness_all45.md);
-    the two outside are named below, strict xfail — on both our energy prefers another fold than the bundled one by < 1 % of E_noe while
+  * best-ENERGY replica (the literal north star): 43 of 45 within +-0.01 (8 seeds: 43 seven times, 42 once: profiles/r04_seed_robustness_all45.md);
+    the two outside are named below, strict xfail — on both our energy prefers another fold than the bundled one (by 0.75 % of E_noe on chr7_1mb, 5 % on chr22_1mb) while
     the bundled fold is present among our 20 replicas (chr22_1mb: the bundled model is the reference's rank 8; chr7_1mb: rank 2);
   * best-SPEARMAN replica (like for like with how the bundled file was chosen): 45 of 45 within +-0.01, bias +0.0009."""
 import glob
