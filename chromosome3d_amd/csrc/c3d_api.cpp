@@ -122,6 +122,7 @@ struct c3d_ctx {
 
     std::vector<int32_t> h_dist10;   // n*n, from K1 (empty when restraints came from a tbl)
     c3d::DevBuffers buf{};
+    bool pair_targets = true;              // option "pair_targets": the per-step kernel's resident row-pair constants (measurement knob)
     float* d_feval = nullptr;
     size_t rep_floats = 0;           // 3*npad per replica
     bool have_targets = false, have_replicas = false;
@@ -317,7 +318,7 @@ void build_program(c3d_ctx* c) {
 }
 
 int upload_targets(c3d_ctx* c, const std::vector<float>& enc) {
-    dev_free(c->buf.tgt);
+    dev_free(c->buf.tgt); dev_free(c->buf.tgs2);
     HIP_TRY(hipMalloc(&c->buf.tgt, sizeof(float) * enc.size()));
     HIP_TRY(hipMemcpyAsync(c->buf.tgt, enc.data(), sizeof(float) * enc.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -380,6 +381,16 @@ int build_targets64(c3d_ctx* c) {
     return C3D_OK;
 }
 
+// Per-step kernel beyond the cluster kernel's reach (no narrow column block: every n > 1024), device potential 4: the resident per-pair
+// constants of row pairs (DevModel::tgs2), built on first use after the targets or the model changed
+int ensure_pair_targets(c3d_ctx* c, const c3d::DevModel& m) {
+    if (c->buf.tgs2 || !c->pair_targets || m.noe_pot != 4 || m.wl != 4 || m.nleft != 0 || c->npad <= 1024 || c->rpw != 2 || !c->buf.tgt) return C3D_OK;
+    HIP_TRY(hipMalloc(&c->buf.tgs2, sizeof(float) * c3d::pair_targets_floats(c->n, c->npad)));
+    hipError_t e = c3d::launch_pair_targets(m, c->buf.tgt, c->buf.tgs2, c->stream);
+    if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("pair targets: ") + hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(c->stream));          // the step launches run on the group streams
+    return C3D_OK;
+}
 // one SA-step launch for replica group g, reading parity `par`
 int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
     c3d::DevModel m = dev_model(c);
@@ -531,6 +542,9 @@ int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w) {
     }
     c->last_path = 0;
     c->ev1_recorded = false;
+    if (c->precision != 64 && !use_sym(c)) {          // (before any stream capture begins: it allocates and synchronises)
+        if (int rc = ensure_pair_targets(c, dev_model(c))) return rc;
+    }
     const int G = active_groups(c);
     // every replica group advances on its own stream (fork from / join into stream 0 around the range): while one
     // group sits in its launch boundary the other computes
@@ -774,7 +788,7 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
     for (int g = 0; g < c3d_ctx::kMaxGroups; ++g) if (c->gstream[g]) hipStreamSynchronize(c->gstream[g]);
     drop_graphs(c);
     free_replica_buffers(c);
-    dev_free(c->buf.tgt);
+    dev_free(c->buf.tgt); dev_free(c->buf.tgs2);
     dev_free(c->d_prog); dev_free(c->d_claim);
     if (c->h_tmo) (void)hipHostFree(c->h_tmo);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -797,6 +811,7 @@ extern "C" int c3d_set_model(c3d_ctx* c, const c3d_model* m) {
     if (c->have_targets && m->min_sep != c->model.min_sep)
         return fail(C3D_ERR_INVALID, "c3d_set_model: min_sep must be set before the targets are built");
     c->model = *m;
+    dev_free(c->buf.tgs2);                 // the pre-scaled pair targets of the per-step kernel carry 1 / mrs: rebuilt on demand
     build_program(c);
     if (c->precision == 64 && c->b64.T) return build_targets64(c);     // the fp64 target matrix encodes "no restraint" per potential
     return C3D_OK;
@@ -840,6 +855,7 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         drop_graphs(c);
         return C3D_OK;
     }
+    if (!strcmp(key, "pair_targets")) { c->pair_targets = value != 0; dev_free(c->buf.tgs2); drop_graphs(c); return C3D_OK; }
     if (!strcmp(key, "symmetric")) {       // takes effect at the next c3d_init_replicas with a new replica count / matrix
         c->sym = value > 0;
         free_replica_buffers(c);
@@ -891,7 +907,7 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     DevTmp<unsigned char> dflags;
     DevTmp<unsigned> dnflag;
     const int npartial = 64;
-    dev_free(c->buf.tgt);
+    dev_free(c->buf.tgt); dev_free(c->buf.tgs2);
     c->have_targets = false;
     HIP_TRY(hipMalloc(&dIF.p, sizeof(double) * nn));
     HIP_TRY(hipMalloc(&dP.p, sizeof(double) * nn));
@@ -939,6 +955,7 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
             const float enc = (sep >= c->model.min_sep && t > 0) ? (float)((double)t / 10.0) : 0.0f;
             HIP_TRY(hipMemcpyAsync(c->buf.tgt + (size_t)i * c->npad + j, &enc, sizeof(float), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            dev_free(c->buf.tgs2);
             ++c->k1_patched;
         }
     }

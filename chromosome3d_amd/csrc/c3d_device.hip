@@ -107,7 +107,10 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     float4 q0 = make_float4(0, 0, 0, 0);
     if (needs_partials && lane < m.ntiles) q0 = pp[lane];
     float4 tv[RPW];
-    if (p.kind != 4) tile_prefetch<RPW, NC>(m, tgt, row0, lane, 0, tv);
+    if (p.kind != 4) {
+        if (pair_targets_in_use<POT, GEN, RPW, NC>(m)) pair_targets_prefetch(m, row0, lane, 0, tv);
+        else tile_prefetch<RPW, NC>(m, tgt, row0, lane, 0, tv);
+    }
     float vx0 = 0.0f, vy0 = 0.0f, vz0 = 0.0f;
     if (finisher && p.kind != 3) {
         const float* vsrc = p.kind == 4 ? vinit : vin;
@@ -158,12 +161,35 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
 hipError_t read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16); }
 #endif
 
+// DevModel::tgs2 from the target matrix: one thread per (row pair, block, lane), eight values
+__global__ __launch_bounds__(256) void k_pair_targets(int n, int npad, float inv_rs, const float* __restrict__ tgt, float* __restrict__ tgs2) {
+    const int nblk = npad >> 8, npairs = (n + 1) / 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)npairs * nblk * 64) return;
+    const int lane = (int)(idx & 63), jb = (int)((idx >> 6) % nblk), q = (int)((idx >> 6) / nblk);
+    const int ra = min(2 * q, n - 1), rb = min(2 * q + 1, n - 1);
+    const float4 a = *reinterpret_cast<const float4*>(tgt + (size_t)ra * npad + 256 * jb + 4 * lane);
+    const float4 b = *reinterpret_cast<const float4*>(tgt + (size_t)rb * npad + 256 * jb + 4 * lane);
+    auto enc = [inv_rs](float t) { return t > 0.0f ? t * inv_rs : 1e30f; };
+    float4* out = reinterpret_cast<float4*>(tgs2 + idx * 8);
+    out[0] = make_float4(enc(a.x), enc(b.x), enc(a.y), enc(b.y));
+    out[1] = make_float4(enc(a.z), enc(b.z), enc(a.w), enc(b.w));
+}
+size_t pair_targets_floats(int n, int npad) { return (size_t)((n + 1) / 2) * (npad >> 8) * 64 * 8; }
+hipError_t launch_pair_targets(const DevModel& m, const float* tgt, float* tgs2, hipStream_t s) {
+    const size_t items = (size_t)((m.n + 1) / 2) * (m.npad >> 8) * 64;
+    hipLaunchKernelGGL(k_pair_targets, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, m.n, m.npad, m.inv_rs, tgt, tgs2);
+    return hipGetLastError();
+}
+
 static size_t step_lds_bytes(const DevModel& m) { return sizeof(float) * ((size_t)3 * m.npad + 4 * kTileRows); }   // xyz + rowq
 
 template <int POT, bool GEN, int RPW>
-static hipError_t launch_step_r(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
+static hipError_t launch_step_r(const DevModel& m0, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
                                 hipStream_t s) {
     const int q = par ^ 1;
+    DevModel m = m0;
+    m.tgs2 = (POT == 4 && !GEN && RPW == 2 && m.wl == 4 && m.nleft == 0) ? b.tgs2 : nullptr;      // (the one kernel that reads it)
     if (m.wl == 4 && m.nleft == 0)      // no narrow last block, no left-over columns: the variant without that code
         hipLaunchKernelGGL((k_step<POT, GEN, RPW, false>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
                            b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);

@@ -40,6 +40,11 @@ struct DevModel {
     float t_fac;                   // T = t_fac * sum(v^2):  mass / kAccel / (ndf * kBoltz)
     float fbeta;
     float inv_n;
+    // Per-step kernel, device potential 4, no narrow column block (every n > 1024): the per-pair constant t / mrs of ROW PAIRS, resident
+    // (Buffers::tgs2, built once per matrix and model by launch_pair_targets): [row pair q][column block jb][lane][column c][row & 1] —
+    // the wave's two rows against its four columns of a block are 32 consecutive bytes, two register-pair-aligned float4 loads — with
+    // "no restraint" encoded as 1e30 (such a pair feels exactly nothing under the decaying lower bound: pair_term2); nullptr = not in use
+    const float* tgs2;
 };
 
 struct DevStep {
@@ -74,6 +79,7 @@ struct FireState {   // per replica, double buffered
 //   S     [2][nrep]            FIRE state
 struct DevBuffers {
     float* tgt;
+    float* tgs2;    // see DevModel::tgs2 (nullptr unless built)
     float* X[2];
     float* V[2];
     float* Vinit;
@@ -90,6 +96,8 @@ hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuff
 hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe,
                          float k_rep, double rep_r2, hipStream_t s);
 hipError_t launch_centre(const DevModel& m, const DevBuffers& b, int parity, hipStream_t s);
+size_t pair_targets_floats(int n, int npad);           // size of DevBuffers::tgs2
+hipError_t launch_pair_targets(const DevModel& m, const float* tgt, float* tgs2, hipStream_t s);
 struct StepRun {    // `count` consecutive steps with the same parameters
     DevStep p;
     int count;

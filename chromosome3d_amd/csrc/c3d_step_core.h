@@ -406,6 +406,19 @@ __device__ __forceinline__ void pair_term2(const PairK2& k, float2v v2, float2v 
     fy2 = __builtin_elementwise_fma(c, dy, fy2);
     fz2 = __builtin_elementwise_fma(c, dz, fz2);
 }
+// DevModel::tgs2 (the pre-scaled targets of row pairs): is this instantiation reading it, and its loads — block jb of the wave's row pair
+// as two float4: (a.x, b.x, a.y, b.y), (a.z, b.z, a.w, b.w)
+template <int POT, bool GEN, int RPW, bool NC>
+__device__ __forceinline__ bool pair_targets_in_use(const DevModel& m) {
+    if constexpr (POT == 4 && !GEN && RPW == 2 && !NC) return m.tgs2 != nullptr; else return false;
+}
+template <int RPW>
+__device__ __forceinline__ void pair_targets_prefetch(const DevModel& m, int row0, int lane, int jb, float4 (&tv)[RPW]) {
+    if constexpr (RPW == 2) {
+        const float4* src = reinterpret_cast<const float4*>(m.tgs2 + (((size_t)(row0 >> 1) * (m.npad >> 8) + jb) * 64 + lane) * 8);
+        tv[0] = src[0]; tv[1] = src[1];
+    }
+}
 // targets streamed from global memory, one column block ahead (per-step kernel)
 // NC = false: the instantiation for problems whose last block is a full one and that leave no column over (m.wl == 4,
 // m.nleft == 0: every N > 1024 among them) carries none of the narrow-column code — the per-step kernel is launched once per SA
@@ -436,21 +449,43 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
 #define C3D_PK_COL(C, SEL, XP, YP, ZP)                                                                                             \
         pair_term2<SEL>(k2, float2v{tv[0].C * m.inv_rs, tv[1].C * m.inv_rs}, float2v{tv[0].C > 0.0f ? on : 0.0f, tv[1].C > 0.0f ? on : 0.0f}, \
                         xi2, yi2, zi2, XP, YP, ZP, fx2, fy2, fz2)
-        for (int jb = 0; jb < nfull; ++jb) {
-            float4 tn[RPW];
-            const int jn = jb + 1 < nblk ? jb + 1 : jb;     // the last block re-reads itself (in bounds)
+        // the targets are streamed TWO column blocks ahead (tv = the block being computed, t1 = the next, the one after it in flight)
+        const bool pairs = pair_targets_in_use<POT, GEN, RPW, NC>(m);
+        const float* trow[RPW];
+        float4 t1[RPW];
 #pragma unroll
-            for (int r = 0; r < RPW; ++r)
-                tn[r] = *reinterpret_cast<const float4*>(tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 256 * jn + 4 * lane);
+        for (int r = 0; r < RPW; ++r) trow[r] = tgt + (size_t)min(row0 + r, m.n - 1) * m.npad + 4 * lane;
+        if (pairs) pair_targets_prefetch<RPW>(m, row0, lane, min(1, nblk - 1), t1);
+        else {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) t1[r] = *reinterpret_cast<const float4*>(trow[r] + 256 * min(1, nblk - 1));
+        }
+        const float2v on2 = float2v{on, on};
+        for (int jb = 0; jb < nfull; ++jb) {
+            float4 t2[RPW];
+            const int jn = min(jb + 2, nblk - 1);           // the last blocks re-read the last one (in bounds)
+            if (pairs) pair_targets_prefetch<RPW>(m, row0, lane, jn, t2);
+            else {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) t2[r] = *reinterpret_cast<const float4*>(trow[r] + 256 * jn);
+            }
             const int j = 256 * jb + 4 * lane;
             const float4 xj = *reinterpret_cast<const float4*>(xs + j);
             const float4 yj = *reinterpret_cast<const float4*>(ys + j);
             const float4 zj = *reinterpret_cast<const float4*>(zs + j);
             const float2v x01 = float2v{xj.x, xj.y}, x23 = float2v{xj.z, xj.w}, y01 = float2v{yj.x, yj.y}, y23 = float2v{yj.z, yj.w};
             const float2v z01 = float2v{zj.x, zj.y}, z23 = float2v{zj.z, zj.w};
-            C3D_PK_COL(x, 0, x01, y01, z01); C3D_PK_COL(y, 1, x01, y01, z01); C3D_PK_COL(z, 0, x23, y23, z23); C3D_PK_COL(w, 1, x23, y23, z23);
+            if (pairs) {
+                // resident per-pair constants of the row pair (DevModel::tgs2): t / mrs or 1e30, nothing to form per step
+                pair_term2<0>(k2, float2v{tv[0].x, tv[0].y}, on2, xi2, yi2, zi2, x01, y01, z01, fx2, fy2, fz2);
+                pair_term2<1>(k2, float2v{tv[0].z, tv[0].w}, on2, xi2, yi2, zi2, x01, y01, z01, fx2, fy2, fz2);
+                pair_term2<0>(k2, float2v{tv[1].x, tv[1].y}, on2, xi2, yi2, zi2, x23, y23, z23, fx2, fy2, fz2);
+                pair_term2<1>(k2, float2v{tv[1].z, tv[1].w}, on2, xi2, yi2, zi2, x23, y23, z23, fx2, fy2, fz2);
+            } else {
+                C3D_PK_COL(x, 0, x01, y01, z01); C3D_PK_COL(y, 1, x01, y01, z01); C3D_PK_COL(z, 0, x23, y23, z23); C3D_PK_COL(w, 1, x23, y23, z23);
+            }
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) tv[r] = tn[r];
+            for (int r = 0; r < RPW; ++r) { tv[r] = t1[r]; t1[r] = t2[r]; }
         }
         if (NC && m.wl != 4) {   // the narrow last block: lanes own m.wl (1..3) consecutive columns
             if (nblk > 1) tile_prefetch<RPW>(m, tgt, row0, lane, nblk - 1, tv);
