@@ -132,3 +132,25 @@ def test_symmetric_tile_step_matches_oracle_and_per_step_kernel(solver, n):
         assert ev == 40
         assert np.abs(xc - xo).max() < 2e-3, np.abs(xc - xo).max()
         assert np.abs(out[1][1][r] - vo).max() < 2e-3 * max(1.0, np.abs(vo).max())
+
+
+def test_resident_pair_targets_change_no_bit(solver):
+    """Beyond the cluster kernel's reach (n > 1024) the per-step kernel of the shipped potential reads pre-scaled targets of row pairs
+    (DevModel::tgs2: t / mrs, "no restraint" as 1e30) instead of forming the pair constants from the target matrix in every step: same
+    operations per restrained pair, an exact zero either way for the others — the trajectories must agree bit for bit (option
+    pair_targets 0 = the constants formed per step).  An odd bead count: the last row pair's second row is a repeat of the last bead."""
+    from chromosome3d_amd import default_fire, default_model, make_stages, pipeline
+    IF, _ = synthetic_if(1101, seed=11)
+    stages = make_stages([(2, 12, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 25, 0.003, 0.4, 0.003, 0.9, 2000.0), (1, 13, 0.005, 1.0, 0.5, 0.9, 1000.0)])
+    out = []
+    for on in (1, 0):
+        solver.set_option("pair_targets", on)
+        solver.set_model(default_model())
+        pipeline.IF2dist_new(solver, IF)
+        solver.set_schedule(stages, default_fire(), 0.0, 250)
+        solver.init_replicas(3, 82364, 0)
+        assert solver.run_steps(10 ** 6) == 50
+        assert "k_step<4, false, 2, false>" in solver.step_kernel_name
+        out.append(solver.coords().copy())
+    solver.set_option("pair_targets", 1)
+    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
