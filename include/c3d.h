@@ -131,6 +131,9 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *                   mark or with a time-out is re-run on the per-step path)
  *   precision       32 (default) or 64: the fp64 reference kernels (c3d_f64.hip); call before c3d_init_replicas
  *   symmetric       1: symmetric-tile kernels for large N (c3d_sym.hip; opt-in); call before c3d_init_replicas
+ *   pair_targets    1 (default) / 0: beyond the multi-step kernel's reach (n > 1024) the per-step kernel of the shipped potential reads
+ *                   resident pre-scaled targets of row pairs (built once per matrix and model) instead of forming the per-pair
+ *                   constants from the target matrix in every step.  Same bits either way (measurement knob)
  *   start           0 (default) random coil, 1 extended strand (chromosome3D.pl:2413-2416)
  *   use_graph       != 0: per-step path replays hipGraphs (default 1)
  *   replica_groups  1..4 stream groups of the per-step path (default 2);  graph_chunk, rows_per_wave,
