@@ -122,6 +122,7 @@ struct c3d_ctx {
 
     std::vector<int32_t> h_dist10;   // n*n, from K1 (empty when restraints came from a tbl)
     c3d::DevBuffers buf{};
+    int eval_rpw = 4;                      // option "eval_rows_per_wave": 4 = scalar pair term in the forces hook, 2 = the packed one, -2 = scalar at two rows per wave
     bool pair_targets = true;              // option "pair_targets": the per-step kernel's resident row-pair constants (measurement knob)
     float* d_feval = nullptr;
     size_t rep_floats = 0;           // 3*npad per replica
@@ -855,6 +856,11 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         drop_graphs(c);
         return C3D_OK;
     }
+    if (!strcmp(key, "eval_rows_per_wave")) {
+        if (value != 2 && value != 4 && value != -2) return fail(C3D_ERR_INVALID, "eval_rows_per_wave must be 4, 2 (packed pair term) or -2 (two rows per wave, scalar pair term)");
+        c->eval_rpw = (int)value;
+        return C3D_OK;
+    }
     if (!strcmp(key, "pair_targets")) { c->pair_targets = value != 0; dev_free(c->buf.tgs2); drop_graphs(c); return C3D_OK; }
     if (!strcmp(key, "symmetric")) {       // takes effect at the next c3d_init_replicas with a new replica count / matrix
         c->sym = value > 0;
@@ -1352,7 +1358,7 @@ extern "C" int c3d_eval(c3d_ctx* c, float w_all, float w_vdw, float repel_s, flo
     const c3d::DevModel m = dev_model(c);
     const c3d::DevStep p = dev_step(c, 3, 0.0f, w_all, w_vdw, repel_s, 0.0f);
     if (F) {
-        hipError_t err = c3d::launch_eval_forces(m, p, c->buf, c->parity, c->d_feval, general_step(m, p), c->stream);
+        hipError_t err = c3d::launch_eval_forces(m, p, c->buf, c->parity, c->d_feval, general_step(m, p), c->eval_rpw, c->stream);
         if (err != hipSuccess) return fail(C3D_ERR_HIP, std::string("eval launch: ") + hipGetErrorString(err));
         int rc = get_soa(c, c->d_feval, F);
         if (rc) return rc;

@@ -231,25 +231,29 @@ hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, c
 // ---------------------------------------------------------------------------------------------
 // Test / scoring hook: forces only, through the same tile_forces<> as the step kernel
 // ---------------------------------------------------------------------------------------------
-template <int POT, bool GEN>
-__global__ __launch_bounds__(kEvalBlock) void k_eval_forces(const DevModel m, const DevStep p,
+// ERPW = rows per wave: 4 (the scalar pair term, what the oracle force tests go through) or, for the shipped potential, 2 in either form of
+// the pair term — packed (pair_term2, the step kernels' code) or scalar: a row's force has the same bits from both, which is what ties
+// the packed form to the scalar one in the test suite (option "eval_rows_per_wave": 4, 2 = packed, -2 = two rows per wave, scalar)
+template <int POT, bool GEN, int ERPW, bool PACKED = true>
+__global__ __launch_bounds__(64 * kTileRows / ERPW) void k_eval_forces(const DevModel m, const DevStep p,
                                                        const float* __restrict__ tgt, const float* __restrict__ xin,
                                                        float* __restrict__ fout) {
+    constexpr int BLOCK = 64 * kTileRows / ERPW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int tile, rep;
     if (!block_to_tile(m, tile, rep)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npad = m.npad;
     const size_t roff = (size_t)rep * 3 * npad;
-    const int row0 = tile * kTileRows + wave * kEvalRowsPerWave;
-    float4 tv[kEvalRowsPerWave];
-    tile_prefetch<kEvalRowsPerWave>(m, tgt, row0, lane, 0, tv);
-    for (int b = tid; b < 3 * npad; b += kEvalBlock) smem[b] = xin[roff + b];
+    const int row0 = tile * kTileRows + wave * ERPW;
+    float4 tv[ERPW];
+    tile_prefetch<ERPW>(m, tgt, row0, lane, 0, tv);
+    for (int b = tid; b < 3 * npad; b += BLOCK) smem[b] = xin[roff + b];
     __syncthreads();
     float Fx, Fy, Fz;
-    tile_forces<POT, GEN, kEvalRowsPerWave>(m, p, tgt, smem, smem + npad, smem + 2 * npad, row0, lane, tv, Fx, Fy, Fz);
+    tile_forces<POT, GEN, ERPW, true, PACKED>(m, p, tgt, smem, smem + npad, smem + 2 * npad, row0, lane, tv, Fx, Fy, Fz);
     const int row = row0 + lane;
-    if (lane < kEvalRowsPerWave && row < m.n) {
+    if (lane < ERPW && row < m.n) {
         fout[roff + row] = Fx;
         fout[roff + npad + row] = Fy;
         fout[roff + 2 * npad + row] = Fz;
@@ -257,12 +261,18 @@ __global__ __launch_bounds__(kEvalBlock) void k_eval_forces(const DevModel m, co
 }
 
 hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float* Fout,
-                              bool general_tail, hipStream_t s) {
+                              bool general_tail, int rows_per_wave, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)3 * m.npad;
     const dim3 g = grid_blocks(m), blk(kEvalBlock);
-#define C3D_EVAL(POT, GEN) hipLaunchKernelGGL((k_eval_forces<POT, GEN>), g, blk, lds, s, m, p, b.tgt, b.X[parity], Fout)
+    static_assert(kEvalRowsPerWave == 4, "the hook's default form is four rows per wave");
+#define C3D_EVAL(POT, GEN) hipLaunchKernelGGL((k_eval_forces<POT, GEN, 4>), g, blk, lds, s, m, p, b.tgt, b.X[parity], Fout)
     if (!general_tail) {
-        if (m.noe_pot == 0) C3D_EVAL(0, false); else if (m.noe_pot == 1) C3D_EVAL(1, false); else if (m.noe_pot == 3) C3D_EVAL(3, false); else if (m.noe_pot == 4) C3D_EVAL(4, false); else C3D_EVAL(2, false);
+        if (m.noe_pot == 0) C3D_EVAL(0, false); else if (m.noe_pot == 1) C3D_EVAL(1, false); else if (m.noe_pot == 3) C3D_EVAL(3, false);
+        else if (m.noe_pot == 4) {
+            if (rows_per_wave == 2) hipLaunchKernelGGL((k_eval_forces<4, false, 2, true>), g, dim3(64 * kTileRows / 2), lds, s, m, p, b.tgt, b.X[parity], Fout);
+            else if (rows_per_wave == -2) hipLaunchKernelGGL((k_eval_forces<4, false, 2, false>), g, dim3(64 * kTileRows / 2), lds, s, m, p, b.tgt, b.X[parity], Fout);
+            else C3D_EVAL(4, false);
+        } else C3D_EVAL(2, false);
     } else {
         if (m.noe_pot == 0) C3D_EVAL(0, true); else if (m.noe_pot == 1) C3D_EVAL(1, true); else if (m.noe_pot == 3) C3D_EVAL(3, true); else if (m.noe_pot == 4) C3D_EVAL(4, true); else C3D_EVAL(2, true);
     }

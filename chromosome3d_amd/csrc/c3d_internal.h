@@ -92,7 +92,7 @@ struct DevBuffers {
 hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int parity,
                        bool general_tail, hipStream_t s);
 hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float* Fout,
-                              bool general_tail, hipStream_t s);
+                              bool general_tail, int rows_per_wave, hipStream_t s);
 hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe,
                          float k_rep, double rep_r2, hipStream_t s);
 hipError_t launch_centre(const DevModel& m, const DevBuffers& b, int parity, hipStream_t s);

@@ -366,6 +366,9 @@ __device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevSte
 // BITS as from the scalar form: the per-step kernel, the forces hook and the left-over columns keep the scalar form, and the
 // bit-identity tests between the launch forms are what checks this code.  16 packed + 6 scalar instructions (v_rsq, v_rcp,
 // v_med3: no packed forms) for two pair terms, against 2 x 19.
+#ifndef C3D_PACKED_STEP
+#define C3D_PACKED_STEP 1          // 0: measurement / test builds with the per-step kernel's pair terms in the scalar form
+#endif
 typedef float float2v __attribute__((ext_vector_type(2)));
 struct PairK2 {
     float2v k0, k1;              // (1e-12, 1 / rep_r2), (kq, rs / mrs): in VGPRs (an SGPR source costs an issue cycle)
@@ -423,7 +426,7 @@ __device__ __forceinline__ void pair_targets_prefetch(const DevModel& m, int row
 // NC = false: the instantiation for problems whose last block is a full one and that leave no column over (m.wl == 4,
 // m.nleft == 0: every N > 1024 among them) carries none of the narrow-column code — the per-step kernel is launched once per SA
 // step and pays for every kilobyte of code it drags along (N = 2500: 26.5 against 27.2 us per step)
-template <int POT, bool GEN, int RPW, bool NC = true>
+template <int POT, bool GEN, int RPW, bool NC = true, bool PACKED = true>
 __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p, const float* __restrict__ tgt,
                                             const float* xs, const float* ys, const float* zs, int row0, int lane,
                                             float4 (&tv)[RPW], float& Fx, float& Fy, float& Fz) {
@@ -439,7 +442,7 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
     // full blocks: every lane owns four columns; the next block's targets are in flight while this one computes.  With a
     // narrow last block (m.wl < 4) the loop stops one block early and the last block follows with its own column map.
     const int nfull = (!NC || m.wl == 4) ? nblk : nblk - 1;
-    if constexpr (POT == 4 && !GEN && RPW == 2) {
+    if constexpr (POT == 4 && !GEN && RPW == 2 && PACKED && C3D_PACKED_STEP) {
         // device potential 4, two rows per wave: the wave's two rows are the row pair of the packed pair term (pair_term2: same bits
         // as the scalar form below, 11 instead of 19 instructions per pair term); the per-pair constants go straight into register pairs
         const PairK2 k2 = pair_k2(m, p);

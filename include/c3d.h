@@ -131,6 +131,9 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *                   mark or with a time-out is re-run on the per-step path)
  *   precision       32 (default) or 64: the fp64 reference kernels (c3d_f64.hip); call before c3d_init_replicas
  *   symmetric       1: symmetric-tile kernels for large N (c3d_sym.hip; opt-in); call before c3d_init_replicas
+ *   eval_rows_per_wave  4 (default) / 2 / -2: form of the forces hook (c3d_eval_forces) — four rows per wave with the scalar pair term; 2 = two
+ *                   rows per wave, the step kernels' code (shipped potential: the packed pair term); -2 = two rows per wave, scalar pair
+ *                   term.  2 and -2 return the same bits (a -m gpu test); test knob
  *   pair_targets    1 (default) / 0: beyond the multi-step kernel's reach (n > 1024) the per-step kernel of the shipped potential reads
  *                   resident pre-scaled targets of row pairs (built once per matrix and model) instead of forming the per-pair
  *                   constants from the target matrix in every step.  Same bits either way (measurement knob)

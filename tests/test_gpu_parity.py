@@ -134,12 +134,19 @@ def _force_energy_case(solver, O, m, d10, x, n, nrep, cid, pot):
     solver.init_replicas(nrep, 1234, 5)
     solver.set_coords(x)
     om = oracle_model_from(m, n)
-    for (w, wv, rs) in [(1.0, 1.0, 0.85), (0.1, 20.0, 0.5), (0.4, 0.003, 0.9)]:
-        F, e = solver.eval(w, wv, rs)
-        for r in range(nrep):
-            Fo, eo = O.energy_force(om, d10, x[r].astype(np.float64), *_f32(w, wv, rs))
-            assert _force_close(F[r], Fo).all(), (cid, pot, w, np.abs(F[r] - Fo).max(), np.abs(Fo).max())
-            assert np.allclose(e[r], eo, rtol=1e-7, atol=1e-6)
+    # the hook's forms: four rows per wave (the scalar pair term) and two (the step kernels' code: for the shipped potential the packed
+    # pair term, c3d_step_core.h pair_term2; the option is ignored by the other potentials)
+    try:
+        for form in (4, 2):
+            solver.set_option("eval_rows_per_wave", form)
+            for (w, wv, rs) in [(1.0, 1.0, 0.85), (0.1, 20.0, 0.5), (0.4, 0.003, 0.9)]:
+                F, e = solver.eval(w, wv, rs)
+                for r in range(nrep):
+                    Fo, eo = O.energy_force(om, d10, x[r].astype(np.float64), *_f32(w, wv, rs))
+                    assert _force_close(F[r], Fo).all(), (cid, pot, form, w, np.abs(F[r] - Fo).max(), np.abs(Fo).max())
+                    assert np.allclose(e[r], eo, rtol=1e-7, atol=1e-6)
+    finally:
+        solver.set_option("eval_rows_per_wave", 4)
 
 
 def test_force_parity_general_tail_and_lower_bound_angle(solver, O):
@@ -805,3 +812,32 @@ def test_random_problems_cluster_kernel_equals_per_step_kernel(solver):
     it, bad, kernels = fuzz(solver, seed=20260, seconds=8.0, out=msgs.append)
     assert bad == 0, msgs
     assert it >= 100 and sum("k_cluster" in k for k in kernels) >= 10, (it, sorted(kernels))
+
+
+@pytest.mark.parametrize("cid", ["chr20_1mb", "chr1_500kb"])
+def test_packed_pair_term_has_the_scalar_forms_bits(solver, cid):
+    """The shipped potential's pair terms run two rows at a time in the packed fp32 forms (pair_term2: cluster kernel, per-step kernel)
+    and one at a time in the scalar form (pair_term<4>: odd rows, left-over columns, and the forces hook at its default four rows per
+    wave — what the oracle force tests go through).  Every component passes through the same operations in the same order and a row's
+    sum keeps its order, so a row's force must have the same bits from both: the hook at two rows per wave with the packed pair term (the
+    step kernels' code) against the same hook with the scalar one, on a compact coil (thousands of pairs beyond the lower switch) and a stretched one, at two
+    stage settings.  (Whole anneals of two builds of the per-step kernel, packed and scalar, end in the same md5:
+    profiles/r04_packed_vs_scalar_coords_hash.txt.)"""
+    from chromosome3d_amd import default_model, pipeline
+    IF = load_if(cid)
+    n = IF.shape[0]
+    solver.set_model(default_model())
+    pipeline.IF2dist_new(solver, IF)
+    solver.init_replicas(3, 82364, 0)
+    x = np.stack([random_coil(n, 1) * 0.35, random_coil(n, 2) * 1.0, random_coil(n, 3) * 3.0]).astype(np.float32)
+    solver.set_coords(x)
+    try:
+        for w_all, w_vdw, repel_s in ((1.0, 1.0, 0.85), (0.1, 20.0, 0.5)):
+            solver.set_option("eval_rows_per_wave", -2)
+            Fs, _ = solver.eval(w_all, w_vdw, repel_s)
+            solver.set_option("eval_rows_per_wave", 2)
+            Fp, _ = solver.eval(w_all, w_vdw, repel_s)
+            assert np.isfinite(Fs).all() and np.abs(Fs).max() > 1.0
+            assert np.array_equal(Fs, Fp), np.abs(Fs - Fp).max()
+    finally:
+        solver.set_option("eval_rows_per_wave", 4)
