@@ -602,7 +602,10 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
         const int threads = (cw + nh) * 64;
         const int kumax = nb > 2 ? 3 : 2;
         // tile sums late (H0 fetches them after B1) where the pair loop outlasts H0's later scalars: rows x column slots of a compute wave
-        const int late = P > 1 && forced_late != 0 && cluster_late_ok(m.noe_pot, rpw, nb, m.wl);
+        // (round 4: what has to outlast H0's later scalars is the pair loop of a SIMD, compute waves x rows x column slots — with the packed
+        //  pair term a lone compute wave per SIMD is through 8 row-slots before them: profiles/r04_late_tiles_ab.txt)
+        const int late = P > 1 && forced_late != 0 && cluster_late_ok(m.noe_pot, rpw, nb, m.wl) &&
+                         (m.noe_pot != 4 || ((cw + 3) / 4) * rpw * (4 * (nb - 1) + m.wl) >= 12);
         if ((late ? m.n : m.n + 2 * ((m.n + 7) / 8)) > (late ? threads - 64 : threads) * kumax) continue;      // gather: units per thread
         // coordinates, sums, row buffers + the compute waves' NOE weights
         size_t lds = sizeof(float) * (3 * m.npad + 4 * (m.npad / 8) + 9 * 64 + 24 * 64 + 16) + (size_t)cw * rpw * nb * 64 * 16;
