@@ -79,9 +79,10 @@ def ensure_ranks(gpus, argv, script=None, module=None, what="bench.py"):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout:                                # rank 0's JSON line comes through here
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in proc.stdout:                                # rank 0's JSON line comes through here; library chatter
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr      # ("[Gloo] Rank 0 is connected ...") goes to stderr
+        out.write(line)
+        out.flush()
     sys.exit(proc.wait())
 
 
