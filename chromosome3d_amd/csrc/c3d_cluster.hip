@@ -568,7 +568,7 @@ hipError_t launch_tear16(int num_cus, void* buf, unsigned* stop, unsigned long l
 // a replica = P = ceil(n / RW) workgroups; the replicas of the fullest XCD must fit its CUs, one or two workgroups per CU.
 // Among the geometries that fit, the cheapest by an instruction-count model of one step (VALU issue is the limiter):
 //   per SIMD: ceil(CW / 4) compute waves x (column slots x instructions per slot of RPW rows + 60) wave-instructions,
-//   + H0's serial tail (~200) + the hand-off (~570 instruction-times = 0.8 us) unless P == 1.
+//   + H0's serial tail (~200) + the hand-off (140 + 0.92 n instruction-times: 0.8 us at n = 455) unless P == 1.
 // Tile sums late (H0 fetches them after B1, LATE = true) where the pair loop of a compute wave — rows x column slots — outlasts
 // H0's later scalars; measured on 13 problems, N = 76 .. 455 (profiles/r03_late_tiles_ab.txt).  Shipped potential only: every
 // (geometry, LATE) pair is one more kernel to compile.
@@ -616,7 +616,9 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
         // form (c3d_step_core.h pair_term2), 19 for an odd last row
         const double per_slot = m.noe_pot == 4 ? (rpw / 2) * 22.0 + (rpw & 1) * 19.0 : rpw * 15.0;
         const double valu = (wps == 1 ? 1.6 : (wps == 2 ? 1.15 : 1.0)) * wps * ((4 * (nb - 1) + m.wl) * per_slot + 60.0);
-        const double serial = 200.0 + (P > 1 ? 570.0 : 0.0);
+        // the hand-off grows with the units gathered (n rows): ~560 instruction-times at n = 455, ~170 at n = 37 (where five small parts of a
+        // replica beat one large workgroup: 1.33 against 1.40 us per step, profiles/r04_cluster_geometry_sweep.txt)
+        const double serial = 200.0 + (P > 1 ? 140.0 + 0.92 * m.n : 0.0);
         // one workgroup per CU: the serial tail of a step follows its pair loop; two per CU: the tails hide behind the
         // other workgroup's loop where there is one
         const double cost = wpc == 1 ? valu + serial : (valu > serial ? valu + 0.35 * serial : 0.5 * valu + serial);
