@@ -231,7 +231,7 @@ hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, c
 // ---------------------------------------------------------------------------------------------
 // Test / scoring hook: forces only, through the same tile_forces<> as the step kernel
 // ---------------------------------------------------------------------------------------------
-// ERPW = rows per wave: 4 (the scalar pair term, what the oracle force tests go through) or, for the shipped potential, 2 in either form of
+// ERPW = rows per wave: 4 (the scalar pair term, what the force tests against the CPU restatement go through) or, for the shipped potential, 2 in either form of
 // the pair term — packed (pair_term2, the step kernels' code) or scalar: a row's force has the same bits from both, which is what ties
 // the packed form to the scalar one in the test suite (option "eval_rows_per_wave": 4, 2 = packed, -2 = two rows per wave, scalar)
 template <int POT, bool GEN, int ERPW, bool PACKED = true>
