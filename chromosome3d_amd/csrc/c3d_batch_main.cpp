@@ -103,14 +103,14 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     TRY(c3d_get_coords(ctx, xyz.data()));
     TRY(c3d_get_energies(ctx, en.data()));
     TRY(c3d_rank(ctx, rank.data()));
-    TRY(c3d_spearman_if_dist_batch(if_copy.data(), xyz.data(), n, M, 3, rho.data()));
+    // Spearman(IF, d) of every model and the satisfaction table's two numbers (:447-485, :581-600) on the device, from the coordinates
+    // resident there (K6, c3d_score_replicas: equal to the host functions c3d_spearman_if_dist_batch / c3d_assess — integers exact, sums
+    // to rounding, a -m gpu test — which took 33 + ~15 ms per chromosome at N = 455, and the 7 MB contact.tbl need not be read back)
+    std::vector<int32_t> sats(M);
+    std::vector<double> devs(M);
+    TRY(c3d_score_replicas(ctx, if_copy.data(), 3, sats.data(), devs.data(), rho.data()));
     const double t_score = now_s();
-    // restraint rows for the satisfaction table (:447-485, :581-600)
-    int32_t *pi = nullptr, *pj = nullptr, *pt = nullptr;
-    int Rt = 0;
-    TRY(c3d_read_tbl(tbl.c_str(), &pi, &pj, &pt, &Rt));
-    std::vector<int32_t> ri(pi, pi + Rt), rj(pj, pj + Rt), rt(pt, pt + Rt);
-    c3d_free(pi); c3d_free(pj); c3d_free(pt);
+    const int Rt = R;                                // rows of contact.tbl = the restraints the context holds
     struct FileCloser {                              // closes the log on every exit path (the TRY macros return early)
         FILE* f;
         ~FileCloser() { if (f) fclose(f); }
@@ -126,9 +126,8 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
         snprintf(name, sizeof name, "%s_%d.pdb", job.id.c_str(), r + 1);
         names[r] = dir + "/" + name;
         TRY(c3d_write_pdb(names[r].c_str(), xyz.data() + (size_t)r * n * 3, n, en[3 * r], en[3 * r + 1], en[3 * r + 2], name));
-        int sat = 0;
-        double dev = 0;
-        TRY(c3d_assess(xyz.data() + (size_t)r * n * 3, n, Rt, ri.data(), rj.data(), rt.data(), 0.5, &sat, &dev));
+        const int sat = sats[r];
+        const double dev = devs[r];
         char cnt[48], sd[48];
         snprintf(cnt, sizeof cnt, "%d/%d", sat, Rt);
         snprintf(sd, sizeof sd, "%.2f", dev);
