@@ -256,8 +256,8 @@ def end_to_end(IF):
             p = subprocess.run(["perl", os.path.join(ROOT, "bin", "chromosome3D_amd.pl"), "-i", mat, "-o", os.path.join(td, "perl_out"), "-m", str(REPLICAS)],
                                capture_output=True, text=True, env=env)
             out["perl_driver_wall_s"] = round(time.perf_counter() - t0, 2) if p.returncode == 0 else None
-            out["perl_driver_note"] = ("perl bin/chromosome3D_amd.pl -i <matrix> -o <dir> -m 20: the reference's CLI and every file it leaves, the satisfaction "
-                                       "table and contact_violation.txt (2.03 M rows) written by the Perl driver itself")
+            out["perl_driver_note"] = ("perl bin/chromosome3D_amd.pl -i <matrix> -o <dir> -m 20: the reference's CLI and every file it leaves; the satisfaction "
+                                       "table and contact_violation.txt (2.03 M rows) come from the library (c3d_write_violations through the XS binding)")
         out["reference_recorded"] = ("chromosome3D.pl on this matrix, measured in the build container on one core (BASELINE.md 2), NOT on this box: Perl front half "
                                      "3.3 s + assessment 4.5 s per model (90 s for 20); its CNS leg cannot run here")
         return out

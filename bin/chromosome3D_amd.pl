@@ -124,7 +124,6 @@ print "Restraints : ".($restraints // "?")." lines in tbl file\n";
 
 # (C) assess models: rank by int(REMARK noe) ascending (:796-802), table (:804-810), top 5 (:822-828)
 print "(C) Assess models..\n";
-my @tbl = read_tbl("contact.tbl");
 my %e_noe;
 foreach my $pdb (glob("./${ID}_*.pdb")) {
 	next if $pdb =~ /_model\d+\.pdb$/;
@@ -137,7 +136,29 @@ foreach my $pdb (glob("./${ID}_*.pdb")) {
 }
 open my $log, ">>", "model_info.log" or die $!;
 print "\nNOE_SATISFIED(+-${DISTRELAX}A)  SUM_OF_DEVIATIONS>= 0.2  PDB\n";
-foreach my $pdb (sort { $e_noe{$b} <=> $e_noe{$a} || $a cmp $b } keys %e_noe) {
+# The satisfaction numbers and the rows of contact_violation.txt (count_satisfied_tbl_rows :447-485, sum_noe_dev :581-600) come from the
+# library (c3d_write_violations: the same arithmetic on the PDB's %8.3f coordinates, the same row format) — through the XS binding or, without
+# it, through c3d_score --assess; 20 models x 101 426 rows take 0.3 s there and 4 s in the Perl loop below, which stays as the last resort.
+my $scorer = dirname($solver)."/c3d_score";
+my $by_lib = ($have_xs and defined &C3D::assess) ? 1 : (-x $scorer ? 2 : 0);
+my @ordered = sort { $e_noe{$b} <=> $e_noe{$a} || $a cmp $b } keys %e_noe;
+if ($by_lib == 1) {
+	my @r = C3D::assess("contact.tbl", $DISTRELAX + 0, "contact_violation.txt", @ordered);      # (count, total, sum_dev) per model
+	foreach my $pdb (@ordered) {
+		my ($count, $total, $sum_dev) = splice(@r, 0, 3);
+		printf "%-9s             %-9s                %-25s\n", "$count/$total", (sprintf "%.2f", $sum_dev), basename($pdb, ".pdb");
+	}
+}
+elsif ($by_lib == 2) {
+	my @out = `@{[shq($scorer)]} --assess contact.tbl $DISTRELAX contact_violation.txt @{[join " ", map { shq($_) } @ordered]}`;
+	die "ERROR! c3d_score --assess failed\n" if $? != 0 or @out != @ordered;
+	foreach my $k (0 .. $#ordered) {
+		die "ERROR! c3d_score --assess: unexpected row $out[$k]\n" if $out[$k] !~ /^(\d+\/\d+)\t(-?[\d.]+)\t/;
+		printf "%-9s             %-9s                %-25s\n", $1, $2, basename($ordered[$k], ".pdb");
+	}
+}
+my @tbl = $by_lib ? () : read_tbl("contact.tbl");
+foreach my $pdb ($by_lib ? () : @ordered) {
 	my %xyz = read_ca($pdb);
 	my ($count, $total, $sum_dev) = (0, 0, 0.0);
 	my (@viol, @ok);   # rows of contact_violation.txt (reference :475-483: violated rows first)

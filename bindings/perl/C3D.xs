@@ -158,3 +158,41 @@ score(matrix_path, pdb_path, range)
         RETVAL = rho;
     OUTPUT:
         RETVAL
+
+void
+assess(tbl_path, relax, viol_path, ...)
+        const char* tbl_path
+        double relax
+        const char* viol_path
+    PREINIT:
+        int32_t *ri = NULL, *rj = NULL, *rt = NULL;
+        int R = 0, k, nm;
+        int* sats = NULL;
+        double* devs = NULL;
+    PPCODE:
+        /* count_satisfied_tbl_rows + sum_noe_dev (chromosome3D.pl:447-485, :581-600) of the model files given after viol_path, in that order:
+           returns (count, total, sum_dev) per model, flattened; viol_path "" = no violation table.  (The results are pushed after the loop:
+           a push inside it would overwrite the argument slots still to be read.) */
+        nm = items - 3;
+        if (c3d_read_tbl(tbl_path, &ri, &rj, &rt, &R) != C3D_OK) croak("C3D::assess: %s", c3d_last_error());
+        Newx(sats, nm > 0 ? nm : 1, int);
+        Newx(devs, nm > 0 ? nm : 1, double);
+        for (k = 0; k < nm; ++k) {
+            const char* pdb_path = SvPV_nolen(ST(k + 3));
+            float* xyz = NULL;
+            int n = 0, rc;
+            sats[k] = 0; devs[k] = 0;
+            if (c3d_read_pdb_ca(pdb_path, &xyz, &n) != C3D_OK) { c3d_free(ri); c3d_free(rj); c3d_free(rt); Safefree(sats); Safefree(devs); croak("C3D::assess: %s", c3d_last_error()); }
+            rc = viol_path[0] ? c3d_write_violations(xyz, n, R, ri, rj, rt, relax, pdb_path, tbl_path, viol_path, &sats[k], &devs[k])
+                              : c3d_assess(xyz, n, R, ri, rj, rt, relax, &sats[k], &devs[k]);
+            c3d_free(xyz);
+            if (rc != C3D_OK) { c3d_free(ri); c3d_free(rj); c3d_free(rt); Safefree(sats); Safefree(devs); croak("C3D::assess: %s", c3d_last_error()); }
+        }
+        c3d_free(ri); c3d_free(rj); c3d_free(rt);
+        EXTEND(SP, 3 * nm);
+        for (k = 0; k < nm; ++k) {
+            mPUSHi(sats[k]);
+            mPUSHi(R);
+            mPUSHn(devs[k]);
+        }
+        Safefree(sats); Safefree(devs);

@@ -1,5 +1,8 @@
 // c3d_score — command-line twin of the reference's spearman_IF_pdb.pl (:15-76):
 //   c3d_score <IF matrix> <pdb file | directory of *.pdb> [range=3]
+// and of its satisfaction report (count_satisfied_tbl_rows :447-485, sum_noe_dev :581-600), for drivers without the in-process binding:
+//   c3d_score --assess <contact.tbl> <relax> <violation file | -> <pdb> [<pdb> ...]
+// prints one row "count/total\tsum_of_deviations\tpdb" per model, in the order given, and appends every model's violation table
 // prints "SRCC\tPDB" rows sorted by descending coefficient (3 decimals), computed by
 // c3d_spearman_if_dist (average-rank Spearman over ordered pairs |i-j| >= range).
 #include <dirent.h>
@@ -13,7 +16,30 @@
 
 #include "../../include/c3d.h"
 
+static int assess_main(int argc, char** argv) {
+    if (argc < 6) { fprintf(stderr, "usage: c3d_score --assess <contact.tbl> <relax> <violation file | -> <pdb> [<pdb> ...]\n"); return 2; }
+    int32_t *ri = nullptr, *rj = nullptr, *rt = nullptr;
+    int R = 0;
+    if (c3d_read_tbl(argv[2], &ri, &rj, &rt, &R) != C3D_OK) { fprintf(stderr, "ERROR! %s\n", c3d_last_error()); return 1; }
+    const double relax = atof(argv[3]);
+    const bool viol = std::string(argv[4]) != "-";
+    for (int k = 5; k < argc; ++k) {
+        float* xyz = nullptr;
+        int n = 0, sat = 0;
+        double dev = 0;
+        if (c3d_read_pdb_ca(argv[k], &xyz, &n) != C3D_OK) { fprintf(stderr, "ERROR! %s\n", c3d_last_error()); return 1; }
+        const int rc = viol ? c3d_write_violations(xyz, n, R, ri, rj, rt, relax, argv[k], argv[2], argv[4], &sat, &dev)
+                            : c3d_assess(xyz, n, R, ri, rj, rt, relax, &sat, &dev);
+        c3d_free(xyz);
+        if (rc != C3D_OK) { fprintf(stderr, "ERROR! %s\n", c3d_last_error()); return 1; }
+        printf("%d/%d\t%.2f\t%s\n", sat, R, dev, argv[k]);
+    }
+    c3d_free(ri); c3d_free(rj); c3d_free(rt);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "--assess") return assess_main(argc, argv);
     if (argc < 3) { fprintf(stderr, "usage: c3d_score <IF matrix> <pdb|dir> [range=3]\n"); return 2; }
     const int range = argc > 3 ? atoi(argv[3]) : 3;
     double* IF = nullptr;

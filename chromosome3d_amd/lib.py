@@ -85,6 +85,7 @@ SIGNATURES = {
     "c3d_shape_pdb": (_i, [C.c_char_p, C.c_char_p, C.c_char_p]),
     "c3d_read_pdb_ca": (_i, [C.c_char_p, C.POINTER(_fp), C.POINTER(_i)]),
     "c3d_assess": (_i, [_fp, _i, _i, _i32p, _i32p, _i32p, _d, C.POINTER(_i), _dp]),
+    "c3d_write_violations": (_i, [_fp, _i, _i, _i32p, _i32p, _i32p, _d, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_i), _dp]),
     "c3d_spearman_if_dist": (_i, [_dp, _fp, _i, _i, _dp]),
     "c3d_spearman_if_dist_batch": (_i, [_dp, _fp, _i, _i, _i, _dp]),
 }

@@ -127,6 +127,16 @@ def assess(xyz, rows, relax=DISTRELAX):
     return sat.value, dev.value
 
 
+def write_violations(xyz, rows, path, pdb_label="model.pdb", tbl_label="contact.tbl", relax=DISTRELAX):
+    """assess() plus the violation table count_satisfied_tbl_rows leaves behind (:475-483), appended to `path`."""
+    ri, rj, rt = (np.ascontiguousarray(a, dtype=np.int32) for a in rows)
+    x = _l.as_f32(xyz)
+    sat, dev = C.c_int(), C.c_double()
+    _l.check(_l.load().c3d_write_violations(_l.fptr(x), x.shape[0], len(ri), _l.i32ptr(ri), _l.i32ptr(rj), _l.i32ptr(rt), relax,
+                                            pdb_label.encode(), tbl_label.encode(), path.encode(), C.byref(sat), C.byref(dev)))
+    return sat.value, dev.value
+
+
 def spearman_IF_pdb(IF, xyz, rng=3):
     """Spearman(IF_ij, d_ij) over ordered pairs |i-j| >= rng; negative for good models."""
     IF = np.ascontiguousarray(IF, dtype=np.float64)

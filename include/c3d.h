@@ -239,6 +239,10 @@ int c3d_shape_pdb(const char* in_path, const char* out_path, const char* log_pat
 /* chromosome3D.pl:447-485, 581-600 on coordinates rounded to 3 decimals as a PDB holds them */
 int c3d_assess(const float* xyz, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10,
                double relax, int* satisfied, double* sum_dev);
+/* The same two numbers and, appended to `path`, the violation table count_satisfied_tbl_rows leaves behind (chromosome3D.pl:475-483): two
+ * '#' lines naming pdb_label and tbl_label, then one row per restraint in the reference's format, violated rows first. */
+int c3d_write_violations(const float* xyz, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10, double relax,
+                         const char* pdb_label, const char* tbl_label, const char* path, int* satisfied, double* sum_dev);
 /* spearman_IF_pdb.pl:42-70 */
 int c3d_spearman_if_dist(const double* IF, const float* xyz, int n, int range, double* rho);
 /* the same for n_models models (n_models*n*3 coordinates) of one matrix: IF is ranked once */

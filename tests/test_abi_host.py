@@ -104,6 +104,40 @@ def test_host_assessment_and_spearman(built, cid):
     assert pipeline.spearman_IF_pdb(IF, X) == pytest.approx(O.spearman_if_dist(IF, X, 3), abs=1e-12)
 
 
+def test_violation_table_equals_the_references_own(built, tmp_path):
+    """A15's file: count_satisfied_tbl_rows (chromosome3D.pl:447-485) leaves contact_violation.txt behind — two '#' lines, then one row
+    per restraint, violated rows first and, inside a flag group, in Perl's hash order (the rows are keys of a hash, :475-483: no two runs
+    of the reference agree on it).  The golden is the reference's own sub run on the bundled chr21_1mb model (tests/golden/make_golden.pl):
+    c3d_write_violations must write the same header, the same MULTISET of rows, the violated ones first, and return the known answers;
+    the command-line twin (c3d_score --assess, what the Perl driver uses without the XS binding) the same."""
+    import subprocess
+    from chromosome3d_amd import pipeline
+    from chromosome3d_amd.lib import LIB_PATH
+    from oracle import oracle as O
+    cid = "chr21_1mb"
+    gold = open(os.path.join(GOLD, f"{cid}.contact_violation.txt")).read().splitlines()
+    rows = O.dist_to_rr(O.if_to_dist10(load_if(cid)))
+    X = load_pdb_xyz(model_pdb(cid))
+    out = tmp_path / "viol.txt"
+    sat, dev = pipeline.write_violations(X, rows, str(out))
+    ours = open(out).read().splitlines()
+    assert f"{sat}/{len(rows[0])}" == G[cid]["satisfied"] and "%.2f" % dev == "%.2f" % G[cid]["sum_dev"]
+    assert ours[:2] == gold[:2] and len(ours) == len(gold) == 2 + len(rows[0])
+    assert sorted(ours[2:]) == sorted(gold[2:])
+    flags = [r[:3] for r in ours[2:]]
+    assert flags == sorted(flags, reverse=True) and [r[:3] for r in gold[2:]] == flags          # violated ("  1") first, as many as the reference has
+    # appended, not overwritten; the CLI twin writes the same table from the files
+    pipeline.write_violations(X, rows, str(out), pdb_label="second.pdb")
+    assert len(open(out).read().splitlines()) == 2 * len(gold)
+    tbl = tmp_path / "contact.tbl"
+    tbl.write_bytes(open(os.path.join(GOLD, f"{cid}.contact.tbl"), "rb").read())
+    v2 = tmp_path / "viol2.txt"
+    r = subprocess.run([os.path.join(os.path.dirname(LIB_PATH), "c3d_score"), "--assess", str(tbl), "0.5", str(v2), model_pdb(cid)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split("\t")[:2] == [G[cid]["satisfied"], "%.2f" % G[cid]["sum_dev"]]
+    assert open(v2).read().splitlines()[2:] == ours[2:]
+
+
 def test_pdb_roundtrip_and_layout(built, tmp_path):
     """Output layout the reference's Perl post-processing expects (parse_pdb_row :674-691,
     get_cns_energy :602-618, add_connect_rows :208-215)."""
