@@ -42,6 +42,7 @@ struct Options {
     double K = 11, alpha = 0.5, gtol = 1e-2;
     int models = 20, min_steps = 3000;
     unsigned long long seed = 82364ULL;
+    bool violations = false;       // --violations: also leave contact_violation.txt (:475-483; 180 MB of text per chromosome at N = 455)
 };
 std::mutex g_print;
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -119,6 +120,7 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     if (!lg) { job.summary = "cannot write the log"; return false; }
     fprintf(lg, "L          : %d\nRestraints : %d lines in tbl file\n\nNOE_SATISFIED(+-0.5A)  SUM_OF_DEVIATIONS>= 0.2  PDB\n", n, R);
     std::vector<std::string> names(M);
+    std::vector<int32_t> vri, vrj, vrt;
     remove((dir + "/model_info.log").c_str());
     for (int k = M - 1; k >= 0; --k) {               // the reference lists (and shapes) from the highest energy down (:805, :813)
         const int r = rank[k];
@@ -126,8 +128,20 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
         snprintf(name, sizeof name, "%s_%d.pdb", job.id.c_str(), r + 1);
         names[r] = dir + "/" + name;
         TRY(c3d_write_pdb(names[r].c_str(), xyz.data() + (size_t)r * n * 3, n, en[3 * r], en[3 * r + 1], en[3 * r + 2], name));
-        const int sat = sats[r];
-        const double dev = devs[r];
+        int sat = sats[r];
+        double dev = devs[r];
+        if (o.violations) {                          // the reference's violation table (and, with it, the host's numbers: the same)
+            if (vri.empty()) {
+                int32_t *pi = nullptr, *pj = nullptr, *pt = nullptr;
+                int Rr = 0;
+                TRY(c3d_read_tbl(tbl.c_str(), &pi, &pj, &pt, &Rr));
+                vri.assign(pi, pi + Rr); vrj.assign(pj, pj + Rr); vrt.assign(pt, pt + Rr);
+                c3d_free(pi); c3d_free(pj); c3d_free(pt);
+                remove((dir + "/contact_violation.txt").c_str());
+            }
+            TRY(c3d_write_violations(xyz.data() + (size_t)r * n * 3, n, (int)vri.size(), vri.data(), vrj.data(), vrt.data(), 0.5, ("./" + std::string(name)).c_str(),
+                                     "contact.tbl", (dir + "/contact_violation.txt").c_str(), &sat, &dev));
+        }
         char cnt[48], sd[48];
         snprintf(cnt, sizeof cnt, "%d/%d", sat, Rt);
         snprintf(sd, sizeof sd, "%.2f", dev);
@@ -207,7 +221,8 @@ int main(int argc, char** argv) {
         else if (s == "--min-steps") o.min_steps = atoi(next("--min-steps"));
         else if (s == "--gtol") o.gtol = atof(next("--gtol"));
         else if (s == "--pattern") pattern = next("--pattern");
-        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text]\n"); return 0; }
+        else if (s == "--violations") o.violations = true;
+        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text] [--violations]\n"); return 0; }
         else inputs.push_back(s);
     }
     if (o.out.empty() || inputs.empty() || o.models < 1) { fprintf(stderr, "c3d_batch: need input matrices and --out <root> (see --help)\n"); return 2; }

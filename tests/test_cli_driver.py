@@ -215,3 +215,14 @@ def test_batch_executor_lanes_do_not_change_results(built, tmp_path):
             a = open(outs[0] / chrom / f"{cid}_model{k}.pdb").read()
             assert a == open(outs[1] / chrom / f"{cid}_model{k}.pdb").read()
             assert a.count("ATOM") == (37 if chrom == "chr21_1mb" else 35) and a.rstrip().endswith("END")
+    # --violations: contact_violation.txt as the reference leaves it (:475-483: 2 + R rows per model, violated rows first), and the
+    # satisfaction table of the log — device numbers without the option, the violation writer's with it — does not change
+    od = tmp_path / "bv"
+    p = subprocess.run([exe, os.path.join(ind, "chr21_1mb_matrix.txt"), "--out", str(od), "--lanes", "1", "-m", "6", "--violations"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    v = open(od / "chr21_1mb" / "contact_violation.txt").read().splitlines()
+    assert len(v) == 6 * (2 + 528) and v[0].startswith("#NOE violation check; ./chr21_1mb_matrix_") and v[0].endswith(" against contact.tbl")
+    flags = [r[:3] for r in v[2:530]]
+    assert flags == sorted(flags, reverse=True) and set(flags) <= {"  1", "  0"}
+    table = lambda d: [l for l in open(d / "chr21_1mb.log").read().splitlines() if "/528" in l]
+    assert len(table(od)) == 6 and table(od) == table(outs[0])
