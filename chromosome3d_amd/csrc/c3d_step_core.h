@@ -366,6 +366,9 @@ __device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevSte
 // BITS as from the scalar form: the per-step kernel, the forces hook and the left-over columns keep the scalar form, and the
 // bit-identity tests between the launch forms are what checks this code.  16 packed + 6 scalar instructions (v_rsq, v_rcp,
 // v_med3: no packed forms) for two pair terms, against 2 x 19.
+#ifndef C3D_PAIR_NONE_AS_FAR
+#define C3D_PAIR_NONE_AS_FAR 1     // cluster kernel, shipped potential: "no restraint" = a target of 1e30 A, no second per-pair constant (0: measurement builds)
+#endif
 #ifndef C3D_PACKED_STEP
 #define C3D_PACKED_STEP 1          // 0: measurement / test builds with the per-step kernel's pair terms in the scalar form
 #endif
@@ -604,9 +607,19 @@ __device__ __forceinline__ void pair_consts2_build(const DevModel& m, const floa
 #pragma unroll
         for (int q = 0; q < RPW / 2; ++q) {
             const float4 ta = traw[2 * q][jb], tb = traw[2 * q + 1][jb];
+#if C3D_PAIR_NONE_AS_FAR
+            // "no restraint" as a target of 1e30 A (as in DevModel::tgs2): under the decaying lower bound such a pair feels exactly nothing, the
+            // second per-pair constant is then 1 / mrs for every pair and need not exist — no 96 KB of LDS per workgroup, no 14 ds_read_b128
+            // per pass of a compute wave
+            auto enc = [&](float t) { return t > 0.0f ? t * m.inv_rs : 1e30f; };
+            pc.p[q][jb][0] = float2v{enc(ta.x), enc(tb.x)}; pc.p[q][jb][1] = float2v{enc(ta.y), enc(tb.y)};
+            pc.p[q][jb][2] = float2v{enc(ta.z), enc(tb.z)}; pc.p[q][jb][3] = float2v{enc(ta.w), enc(tb.w)};
+            if (false) {
+#else
             pc.p[q][jb][0] = float2v{ta.x * m.inv_rs, tb.x * m.inv_rs}; pc.p[q][jb][1] = float2v{ta.y * m.inv_rs, tb.y * m.inv_rs};
             pc.p[q][jb][2] = float2v{ta.z * m.inv_rs, tb.z * m.inv_rs}; pc.p[q][jb][3] = float2v{ta.w * m.inv_rs, tb.w * m.inv_rs};
             if (store) {
+#endif
                 const float on = m.inv_rs;
                 mw_lds[((q * NB + jb) * 2) * 64 + lane] = make_float4(ta.x > 0.0f ? on : 0.0f, tb.x > 0.0f ? on : 0.0f, ta.y > 0.0f ? on : 0.0f, tb.y > 0.0f ? on : 0.0f);
                 mw_lds[((q * NB + jb) * 2 + 1) * 64 + lane] = make_float4(ta.z > 0.0f ? on : 0.0f, tb.z > 0.0f ? on : 0.0f, ta.w > 0.0f ? on : 0.0f, tb.w > 0.0f ? on : 0.0f);
@@ -630,6 +643,10 @@ __device__ __forceinline__ void tile_pair_sums_pk(const DevModel& m, const DevSt
     const PairK2 k2 = pair_k2(m, p);
     PairK k{};
     if constexpr (RPW & 1) k = pair_k(m, p);
+#if C3D_PAIR_NONE_AS_FAR
+    float2v on2 = float2v{m.inv_rs, m.inv_rs};
+    asm volatile("" : "+v"(on2));
+#endif
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int ra = min(row0 + 2 * q, m.n - 1), rb = min(row0 + 2 * q + 1, m.n - 1);
@@ -654,11 +671,17 @@ __device__ __forceinline__ void tile_pair_sums_pk(const DevModel& m, const DevSt
         const float2v z01 = float2v{zj.x, zj.y}, z23 = float2v{zj.z, zj.w};
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
+#if C3D_PAIR_NONE_AS_FAR
+            const float4 ma = make_float4(on2.x, on2.y, on2.x, on2.y), mb = ma;
+#else
             const float4 ma = mw_lds[((q * NB + jb) * 2) * 64 + lane];
+#endif
             pair_term2<0>(k2, pc.p[q][jb][0], float2v{ma.x, ma.y}, xi2[q], yi2[q], zi2[q], x01, y01, z01, fx2[q], fy2[q], fz2[q]);
             if (width > 1) pair_term2<1>(k2, pc.p[q][jb][1], float2v{ma.z, ma.w}, xi2[q], yi2[q], zi2[q], x01, y01, z01, fx2[q], fy2[q], fz2[q]);
             if (width > 2) {
+#if !C3D_PAIR_NONE_AS_FAR
                 const float4 mb = mw_lds[((q * NB + jb) * 2 + 1) * 64 + lane];
+#endif
                 pair_term2<0>(k2, pc.p[q][jb][2], float2v{mb.x, mb.y}, xi2[q], yi2[q], zi2[q], x23, y23, z23, fx2[q], fy2[q], fz2[q]);
                 if (width > 3) pair_term2<1>(k2, pc.p[q][jb][3], float2v{mb.z, mb.w}, xi2[q], yi2[q], zi2[q], x23, y23, z23, fx2[q], fy2[q], fz2[q]);
             }
