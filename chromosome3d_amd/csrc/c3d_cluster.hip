@@ -220,7 +220,8 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
 #endif
     // per-pair constants of the clamp form (c3d_step_core.h: pair_b = target / rswitch in registers, pair_a = 1 / rswitch where
     // a restraint exists in wave-private LDS), the same for every step of the launch
-    // (device potential 4, the shipped model: row PAIRS per column, the layout of the packed pair term — c3d_step_core.h pair_term2)
+    // (device potential 4, the shipped model: row PAIRS per column, the layout of the packed pair term — c3d_step_core.h pair_term2 —, "no
+    //  restraint" as a target of 1e30 A, so that the second constant is 1 / mrs for every pair and only an odd last row keeps it in LDS)
     constexpr bool PK = POT == 4;
     float4 tv[PK ? 1 : RPW][NB];
     PairConsts2<PK ? RPW : 1, NB> pc;
