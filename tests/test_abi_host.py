@@ -138,6 +138,25 @@ def test_violation_table_equals_the_references_own(built, tmp_path):
     assert open(v2).read().splitlines()[2:] == ours[2:]
 
 
+def test_violation_writer_error_behaviour(built, tmp_path):
+    """Status codes, not crashes: a restraint row outside the model, an unwritable path, null arguments."""
+    import ctypes as C
+    from chromosome3d_amd import pipeline
+    from chromosome3d_amd.lib import C3DError, load
+    x = np.zeros((5, 3), dtype=np.float32)
+    rows = (np.array([1], dtype=np.int32), np.array([9], dtype=np.int32), np.array([100], dtype=np.int32))
+    with pytest.raises(C3DError, match="out of range"):
+        pipeline.write_violations(x, rows, str(tmp_path / "v.txt"))
+    assert not (tmp_path / "v.txt").exists()                                  # nothing is written before the rows have been checked
+    ok = (np.array([1], dtype=np.int32), np.array([5], dtype=np.int32), np.array([100], dtype=np.int32))
+    with pytest.raises(C3DError, match="cannot open"):
+        pipeline.write_violations(x, ok, str(tmp_path / "no_such_dir" / "v.txt"))
+    assert load().c3d_write_violations(None, 5, 0, None, None, None, 0.5, None, None, None, None, None) != 0
+    sat, dev = pipeline.write_violations(x, ok, str(tmp_path / "v.txt"))       # d = 0 against a 10 A target: below the lower bound
+    assert (sat, dev) == (0, 10.0)
+    assert open(tmp_path / "v.txt").read().splitlines()[2] == "  1\t-10.00\t0.00 # assign45  resid   1 and name ca   resid   5 and name ca  10.00 0.00 0.00"
+
+
 def test_pdb_roundtrip_and_layout(built, tmp_path):
     """Output layout the reference's Perl post-processing expects (parse_pdb_row :674-691,
     get_cns_energy :602-618, add_connect_rows :208-215)."""
