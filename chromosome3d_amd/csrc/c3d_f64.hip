@@ -36,6 +36,9 @@ struct Model64 {
 struct Step64 {
     int kind;
     double dt, w_all, w_vdw, repel_s, t_bath;
+    // uniform factors of a step, formed on the host (fp64 has no scalar ALU: formed in the kernel they are vector registers every wave
+    // holds through its pair loop): R2 = (repel_s r0_rep)^2, wr4 = 4 w_vdw k_rep, nws4 = -4 w_all S, wq = wr4 / nws4 (0 where nws4 = 0)
+    double R2, wr4, nws4, wq;
 };
 struct Fire64 {
     double dt_start, dt_max, f_inc, f_dec, alpha_start, f_alpha, max_step;
@@ -135,7 +138,10 @@ __device__ __forceinline__ double half_noe_grad64(const Model64& m, double delta
         else if constexpr (POT == 4) {
             // lower side beyond mrs: dE/dD = 2 mrs^4 / D^3 (soft form, exponent 2, no asymptote) = the lower bound -mrs (mrs / D)^3 of
             // the same clamp; 1 / D from v_rcp_f64 and two Newton steps, D held at >= mrs (the bound is -mrs inside the square part)
-            const double D = fmax(-delta, m.mrs);
+            // D = |delta| (a free source modifier; round 4, second session: it was max(-delta, mrs)): inside the square part and above the
+            // target the bound -mrs^4 / D^3 then lies BELOW delta and does not bind; delta = 0 (or below the fp32 seed's range): the seed is
+            // inf, the Newton step NaN, and max(delta, NaN) = delta
+            const double D = fabs(delta);
             double y = (double)__builtin_amdgcn_rcpf((float)D);
             double e = fma(-D, y, 1.0);
             y = fma(y, e, y);
@@ -162,7 +168,9 @@ __device__ __forceinline__ double half_noe_grad64(const Model64& m, double delta
 //   NOE    -w S g(d - T) / d = nws4 * (g / 2) * h,  nws4 = -4 w S where restrained else 0, h = 1 / (2 d)
 //   repel  on EVERY column: 4 w_vdw k_rep max(0, R2 - r2); the self term has dx = 0, the |i-j| < rep_sep neighbours are taken
 //          back out with the chain terms (chain64)
-template <int POT, bool GEN>
+// FOLD (fast soft lower side only): the row's sum is formed WITHOUT the NOE weight — nws4 = 1 here, wr4 = the repel weight divided by the NOE
+// weight — and multiplied by it once per row (k64_step): one multiplication less per pair term.  Needs a non-zero NOE weight.
+template <int POT, bool GEN, bool FOLD = false>
 __device__ __forceinline__ void pair64(const Model64& m, double nws4, double wr4, double R2, double T, double xi, double yi, double zi,
                                        double xj, double yj, double zj, double& fx, double& fy, double& fz) {
     const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
@@ -176,7 +184,8 @@ __device__ __forceinline__ void pair64(const Model64& m, double nws4, double wr4
     // T = kNoTarget64 = 1e300 instead: a pair that far inside its "target" feels exactly nothing (D = 1e300: the fp32 seed of 1 / D is 0, the
     // Newton steps keep it, the bound is -0, the force +0), which saves the compare and the two selects of every pair term
     if constexpr (!(POT == 4 && !GEN)) wn = T > 0.0 ? nws4 : 0.0;
-    const double cn = wn * (half_noe_grad64<POT, GEN>(m, d - T) * h);
+    double cn = half_noe_grad64<POT, GEN>(m, d - T) * h;
+    if constexpr (!(FOLD && POT == 4 && !GEN)) cn = wn * cn;
     const double coef = fma(wr4, fmax(R2 - r2, 0.0), cn);
     fx = fma(coef, dx, fx); fy = fma(coef, dy, fy); fz = fma(coef, dz, fz);
 }
@@ -199,7 +208,7 @@ __device__ __forceinline__ void chain64(const Model64& m, const Step64& p, doubl
 }
 
 // P: [nrep][ntiles][4] per-tile sums of the previous step — MD kinds: (sum v^2, sum vx, vy, vz); FIRE: (v.F, F.F, v.v, 0)
-template <int POT, bool GEN>
+template <int POT, bool GEN, bool FOLD = false>
 __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) void k64_step(const Model64 m, const Step64 p, const Fire64 fp, const int rep_base,
                                                     const double* __restrict__ T, const double* __restrict__ xin,
                                                     const double* __restrict__ vin, const double* __restrict__ vinit,
@@ -274,11 +283,12 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
 
     // ---- pair forces of this wave's two rows ----
     double fxa = 0, fya = 0, fza = 0, fxb = 0, fyb = 0, fzb = 0;
-    const double R2 = (p.repel_s * m.r0_rep) * (p.repel_s * m.r0_rep);
-    const double wr4 = p.w_vdw * m.k_rep * 4.0;
+    const double R2 = p.R2;
+    const double wr4 = p.wr4;
     if (p.kind != 4) {
         const double xa = xs[ra], ya = ys[ra], za = zs[ra], xb = xs[rb], yb = ys[rb], zb = zs[rb];
-        const double nws4 = -4.0 * p.w_all * m.s_noe;
+        // (FOLD: the pair terms carry the repel weight relative to the NOE weight, the row sums get the NOE weight below)
+        const double nws4p = FOLD ? 1.0 : p.nws4, wr4p = FOLD ? p.wq : wr4;
         // Columns: two per lane and pass (j, j + 64) over the first n & ~127 of them, the next two in flight while these two compute; then
         // ONE column per lane if 64 or more are left, then the last n % 64 columns — both rows of the wave in one pass where they fit
         // (lane = (row, column)).  No lane evaluates a padding column pair by pair any more (455 beads: 15 pair terms per lane, not 16);
@@ -290,10 +300,10 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
                 Ta += jn; Tb += jn;
                 const double na0 = Ta[0], na1 = Ta[64], nb0 = Tb[0], nb1 = Tb[64];
                 const double x0 = xs[j], y0 = ys[j], z0 = zs[j], x1 = xs[j + 64], y1 = ys[j + 64], z1 = zs[j + 64];
-                pair64<POT, GEN>(m, nws4, wr4, R2, ta0, xa, ya, za, x0, y0, z0, fxa, fya, fza);
-                pair64<POT, GEN>(m, nws4, wr4, R2, tb0, xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
-                pair64<POT, GEN>(m, nws4, wr4, R2, ta1, xa, ya, za, x1, y1, z1, fxa, fya, fza);
-                pair64<POT, GEN>(m, nws4, wr4, R2, tb1, xb, yb, zb, x1, y1, z1, fxb, fyb, fzb);
+                pair64<POT, GEN, FOLD>(m, nws4p, wr4p, R2, ta0, xa, ya, za, x0, y0, z0, fxa, fya, fza);
+                pair64<POT, GEN, FOLD>(m, nws4p, wr4p, R2, tb0, xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
+                pair64<POT, GEN, FOLD>(m, nws4p, wr4p, R2, ta1, xa, ya, za, x1, y1, z1, fxa, fya, fza);
+                pair64<POT, GEN, FOLD>(m, nws4p, wr4p, R2, tb1, xb, yb, zb, x1, y1, z1, fxb, fyb, fzb);
                 ta0 = na0; ta1 = na1; tb0 = nb0; tb1 = nb1;
             }
         }
@@ -303,8 +313,8 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
         if (n - c0 >= 64) {
             const int j = c0 + lane;
             const double x0 = xs[j], y0 = ys[j], z0 = zs[j];
-            pair64<POT, GEN>(m, nws4, wr4, R2, Tra[j], xa, ya, za, x0, y0, z0, fxa, fya, fza);
-            pair64<POT, GEN>(m, nws4, wr4, R2, Trb[j], xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
+            pair64<POT, GEN, FOLD>(m, nws4p, wr4p, R2, Tra[j], xa, ya, za, x0, y0, z0, fxa, fya, fza);
+            pair64<POT, GEN, FOLD>(m, nws4p, wr4p, R2, Trb[j], xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
             c0 += 64;
         }
         const int left = n - c0;                             // 0 .. 63 columns
@@ -314,16 +324,17 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
             const int j = c < left ? c0 + c : n;
             const double xr = second ? xb : xa, yr = second ? yb : ya, zr = second ? zb : za;
             double tx = 0, ty = 0, tz = 0;
-            pair64<POT, GEN>(m, nws4, wr4, R2, (second ? Trb : Tra)[j], xr, yr, zr, xs[j], ys[j], zs[j], tx, ty, tz);
+            pair64<POT, GEN, FOLD>(m, nws4p, wr4p, R2, (second ? Trb : Tra)[j], xr, yr, zr, xs[j], ys[j], zs[j], tx, ty, tz);
             if (second) { fxb += tx; fyb += ty; fzb += tz; } else { fxa += tx; fya += ty; fza += tz; }
         } else if (left > 0) {
             const int j = lane < left ? c0 + lane : n;
             const double x0 = xs[j], y0 = ys[j], z0 = zs[j];
-            pair64<POT, GEN>(m, nws4, wr4, R2, Tra[j], xa, ya, za, x0, y0, z0, fxa, fya, fza);
-            pair64<POT, GEN>(m, nws4, wr4, R2, Trb[j], xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
+            pair64<POT, GEN, FOLD>(m, nws4p, wr4p, R2, Tra[j], xa, ya, za, x0, y0, z0, fxa, fya, fza);
+            pair64<POT, GEN, FOLD>(m, nws4p, wr4p, R2, Trb[j], xb, yb, zb, x0, y0, z0, fxb, fyb, fzb);
         }
     }
     double Fx = reduce_rows64(fxa, fxb, lane), Fy = reduce_rows64(fya, fyb, lane), Fz = reduce_rows64(fza, fzb, lane);
+    if constexpr (FOLD) { Fx *= p.nws4; Fy *= p.nws4; Fz *= p.nws4; }
     // chain terms: lane 4 r + nb evaluates neighbour nb (offsets -2, -1, +1, +2) of row row0 + r; quad sum; to lane r
     {
         const int r = (lane >> 2) & 1, nb = lane & 3;
@@ -440,6 +451,10 @@ hipError_t launch_step64(const DevModel& d, const double* model_host, const doub
     const Model64 m = model64(d, model_host);
     Step64 p;   // step_host[]: kind, dt, w_all, w_vdw, repel_s, t_bath
     p.kind = (int)step_host[0]; p.dt = step_host[1]; p.w_all = step_host[2]; p.w_vdw = step_host[3]; p.repel_s = step_host[4]; p.t_bath = step_host[5];
+    p.R2 = (p.repel_s * m.r0_rep) * (p.repel_s * m.r0_rep);
+    p.wr4 = p.w_vdw * m.k_rep * 4.0;
+    p.nws4 = -4.0 * p.w_all * m.s_noe;
+    p.wq = p.nws4 != 0.0 ? p.wr4 / p.nws4 : 0.0;
     Fire64 fp;
     fp.dt_start = fire_host[0]; fp.dt_max = fire_host[1]; fp.f_inc = fire_host[2]; fp.f_dec = fire_host[3]; fp.alpha_start = fire_host[4];
     fp.f_alpha = fire_host[5]; fp.max_step = fire_host[6]; fp.n_min = fire_n_min;
@@ -452,7 +467,11 @@ hipError_t launch_step64(const DevModel& d, const double* model_host, const doub
                                                 b.P[parity], sin, b.X[q], b.V[q], b.P[q], sout)
     if (!general64(m)) {
         if (m.noe_pot == 0) C3D_STEP64(0, false); else if (m.noe_pot == 1) C3D_STEP64(1, false); else if (m.noe_pot == 3) C3D_STEP64(3, false);
-        else if (m.noe_pot == 4) C3D_STEP64(4, false); else C3D_STEP64(2, false);
+        else if (m.noe_pot == 4) {
+            if (p.w_all != 0.0) hipLaunchKernelGGL((k64_step<4, false, true>), grid, blk, lds, s, m, p, fp, d.rep_base, b.T, b.X[parity], b.V[parity], b.Vinit, b.P[parity],
+                                                   sin, b.X[q], b.V[q], b.P[q], sout);
+            else C3D_STEP64(4, false);
+        } else C3D_STEP64(2, false);
     } else {
         if (m.noe_pot == 0) C3D_STEP64(0, true); else if (m.noe_pot == 1) C3D_STEP64(1, true); else if (m.noe_pot == 3) C3D_STEP64(3, true); else C3D_STEP64(2, true);
     }
