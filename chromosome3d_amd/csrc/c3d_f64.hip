@@ -39,6 +39,10 @@ struct Step64 {
     // uniform factors of a step, formed on the host (fp64 has no scalar ALU: formed in the kernel they are vector registers every wave
     // holds through its pair loop): R2 = (repel_s r0_rep)^2, wr4 = 4 w_vdw k_rep, nws4 = -4 w_all S, wq = wr4 / nws4 (0 where nws4 = 0)
     double R2, wr4, nws4, wq;
+    double acc;        // MD: dt kAccel / mass (the kernel's own division was ~30 fp64 operations on every wave's path after its pair loop)
+    double kb4, ka4;   // chain terms: -4 w_all k_bond, -4 w_all k_ang
+    double kacc;       // kAccel / mass (FIRE: times the step's dt)
+    double a0sq;       // a0^2
 };
 struct Fire64 {
     double dt_start, dt_max, f_inc, f_dec, alpha_start, f_alpha, max_step;
@@ -201,8 +205,8 @@ __device__ __forceinline__ void chain64(const Model64& m, const Step64& p, doubl
     double d, h;
     sqrt_hrsqrt64(r2, d, h);                          // h = 1 / (2 d)
     double coef = 0.0;
-    if (sep == 1) coef = -p.w_all * 4.0 * m.k_bond * (d - m.b0) * h;
-    else if (m.k_ang > 0 && (m.ang_mode == 1 || r2 < m.a0 * m.a0)) coef = -p.w_all * 4.0 * m.k_ang * (d - m.a0) * h;
+    if (sep == 1) coef = p.kb4 * (d - m.b0) * h;
+    else if (m.k_ang > 0 && (m.ang_mode == 1 || r2 < p.a0sq)) coef = p.ka4 * (d - m.a0) * h;
     if (sep < m.rep_sep) coef -= wr4 * fmax(R2 - r2, 0.0);      // the pair loop applied the repel term to every column
     cx = coef * dx; cy = coef * dy; cz = coef * dz;
 }
@@ -358,13 +362,13 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
             vx = v0x; vy = v0y; vz = v0z; xn = x0; yn = y0; zn = z0;
             q0 = vx * vx + vy * vy + vz * vz; q1 = vx; q2 = vy; q3 = vz;
         } else if (p.kind == 0 || p.kind == 1) {
-            const double acc = p.dt * kAccel64 / m.mass;
+            const double acc = p.acc;
             vx = lam * (v0x - cm0) + acc * Fx; vy = lam * (v0y - cm1) + acc * Fy; vz = lam * (v0z - cm2) + acc * Fz;
             xn = x0 + p.dt * vx; yn = y0 + p.dt * vy; zn = z0 + p.dt * vz;
             q0 = vx * vx + vy * vy + vz * vz; q1 = vx; q2 = vy; q3 = vz;
         } else {
             q0 = v0x * Fx + v0y * Fy + v0z * Fz; q1 = Fx * Fx + Fy * Fy + Fz * Fz; q2 = v0x * v0x + v0y * v0y + v0z * v0z;
-            const double acc = st.dt * kAccel64 / m.mass;
+            const double acc = st.dt * p.kacc;
             vx = keep * v0x + mix * Fx; vy = keep * v0y + mix * Fy; vz = keep * v0z + mix * Fz;
             vx += acc * Fx; vy += acc * Fy; vz += acc * Fz;
             const double dxs = st.dt * vx, dys = st.dt * vy, dzs = st.dt * vz;
@@ -455,6 +459,10 @@ hipError_t launch_step64(const DevModel& d, const double* model_host, const doub
     p.wr4 = p.w_vdw * m.k_rep * 4.0;
     p.nws4 = -4.0 * p.w_all * m.s_noe;
     p.wq = p.nws4 != 0.0 ? p.wr4 / p.nws4 : 0.0;
+    p.acc = p.dt * kAccel64 / m.mass;
+    p.kb4 = -p.w_all * 4.0 * m.k_bond; p.ka4 = -p.w_all * 4.0 * m.k_ang;
+    p.kacc = kAccel64 / m.mass;
+    p.a0sq = m.a0 * m.a0;
     Fire64 fp;
     fp.dt_start = fire_host[0]; fp.dt_max = fire_host[1]; fp.f_inc = fire_host[2]; fp.f_dec = fire_host[3]; fp.alpha_start = fire_host[4];
     fp.f_alpha = fire_host[5]; fp.max_step = fire_host[6]; fp.n_min = fire_n_min;
