@@ -476,39 +476,80 @@ extern "C" int c3d_write_violations(const float* xyz, int n, int R, const int32_
     return C3D_OK;
 }
 
-static void avg_ranks(const std::vector<double>& v, std::vector<double>& r) {
+// average ranks (1-based, ties share the mean of their positions).  The values are sorted as (order-preserving 64-bit key, index) records by
+// an LSD radix sort, 11 bits a pass, passes whose digit is the same for every value skipped — an indirect std::sort of 2 x 10^5 indices
+// misses the cache at every comparison (18 -> 7 ms at N = 455 where both were timed).  The ranks do not depend on how ties are ordered.
+// `copies` = 2 ranks the multiset in which every value appears twice (a symmetric matrix given by its upper half): the tie group at
+// half-list positions k..e sits at 2k..2e+1 of the full list, so its rank is k + e + 1.5 — exact, and the same double the full sort gives.
+static inline uint64_t order_key(double d) {
+    uint64_t u;
+    memcpy(&u, &d, 8);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+static void avg_ranks(const std::vector<double>& v, std::vector<double>& r, int copies = 1) {
+    struct KV { uint64_t k; uint32_t i; };
     const size_t m = v.size();
-    std::vector<uint32_t> idx(m);
-    for (size_t k = 0; k < m; ++k) idx[k] = (uint32_t)k;
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return v[a] < v[b]; });
+    std::vector<KV> kv(m), tmp(m);
+    for (size_t k = 0; k < m; ++k) kv[k] = KV{order_key(v[k]), (uint32_t)k};
+    constexpr int B = 11, P = 6, R = 1 << B;
+    std::vector<uint32_t> hist((size_t)P * R, 0);
+    for (size_t k = 0; k < m; ++k)
+        for (int p = 0; p < P; ++p) ++hist[(size_t)p * R + ((kv[k].k >> (p * B)) & (R - 1))];
+    KV *src = kv.data(), *dst = tmp.data();
+    for (int p = 0; p < P; ++p) {
+        uint32_t* h = &hist[(size_t)p * R];
+        bool one_digit = false;
+        for (int d = 0; d < R && !one_digit; ++d) one_digit = h[d] == m;
+        if (one_digit) continue;
+        uint32_t at = 0;
+        for (int d = 0; d < R; ++d) { const uint32_t c = h[d]; h[d] = at; at += c; }
+        for (size_t k = 0; k < m; ++k) { const KV e = src[k]; dst[h[(e.k >> (p * B)) & (R - 1)]++] = e; }
+        std::swap(src, dst);
+    }
     r.resize(m);
     size_t k = 0;
     while (k < m) {
         size_t e = k;
-        while (e + 1 < m && v[idx[e + 1]] == v[idx[k]]) ++e;
-        const double rank = 0.5 * ((double)k + (double)e) + 1.0;
-        for (size_t q = k; q <= e; ++q) r[idx[q]] = rank;
+        const double vk = v[src[k].i];
+        while (e + 1 < m && v[src[e + 1].i] == vk) ++e;      // -0.0 and +0.0 have adjacent keys and compare equal here
+        const double rank = copies == 2 ? ((double)k + (double)e) + 1.5 : 0.5 * ((double)k + (double)e) + 1.0;
+        for (size_t q = k; q <= e; ++q) r[src[q].i] = rank;
         k = e + 1;
     }
 }
 
+// ranks of the ordered pairs |i-j| >= range of IF (spearman_IF_pdb.pl:30-44 ranks both (i,j) and (j,i)).  A symmetric matrix — every matrix
+// the pipeline makes — is ranked from its upper half; the sums run over the ordered pairs in the reference's order either way.
 void c3d::if_pair_ranks(const double* IF, int n, int range, std::vector<double>& rank_matrix, size_t& m, double& mean_rank, double& saa) {
     std::vector<double> a, ra;
     std::vector<size_t> pos;
+    bool symmetric = true;
+    for (int i = 0; i < n && symmetric; ++i)
+        for (int j = i + (range > 0 ? range : 0); j < n; ++j)
+            if (IF[(size_t)i * n + j] != IF[(size_t)j * n + i]) { symmetric = false; break; }
+    if (range <= 0) symmetric = false;                         // the diagonal would be counted once, not twice
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
+        for (int j = symmetric ? i + range : 0; j < n; ++j) {
             if (std::abs(i - j) < range) continue;
             a.push_back(IF[(size_t)i * n + j]);
             pos.push_back((size_t)i * n + j);
         }
-    m = a.size();
     rank_matrix.assign((size_t)n * n, 0.0);
-    mean_rank = 0; saa = 0;
-    if (m == 0) return;
-    avg_ranks(a, ra);
-    for (size_t k = 0; k < m; ++k) { rank_matrix[pos[k]] = ra[k]; mean_rank += ra[k]; }
+    mean_rank = 0; saa = 0; m = 0;
+    if (a.empty()) return;
+    avg_ranks(a, ra, symmetric ? 2 : 1);
+    for (size_t k = 0; k < a.size(); ++k) {
+        rank_matrix[pos[k]] = ra[k];
+        if (symmetric) rank_matrix[(pos[k] % n) * n + pos[k] / n] = ra[k];
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (std::abs(i - j) >= range) { mean_rank += rank_matrix[(size_t)i * n + j]; ++m; }
     mean_rank /= (double)m;
-    for (size_t k = 0; k < m; ++k) saa += (ra[k] - mean_rank) * (ra[k] - mean_rank);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (std::abs(i - j) >= range) { const double d = rank_matrix[(size_t)i * n + j] - mean_rank; saa += d * d; }
 }
 
 // Spearman for M models of one matrix: the IF ranks are computed once; distances are integers in
@@ -516,23 +557,19 @@ void c3d::if_pair_ranks(const double* IF, int n, int range, std::vector<double>&
 // ranks come from a counting pass instead of a sort.
 extern "C" int c3d_spearman_if_dist_batch(const double* IF, const float* xyz, int n, int n_models, int range, double* rho) {
     if (!IF || !xyz || !rho || n < 2 || n_models < 1) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist_batch: bad arguments");
+    std::vector<double> rank_matrix, ra;
+    size_t m = 0;
+    double ma = 0, saa = 0;
+    c3d::if_pair_ranks(IF, n, range, rank_matrix, m, ma, saa);
+    if (m < 2) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist_batch: range leaves no pairs");
     std::vector<uint32_t> pi, pj;
-    std::vector<double> a;
+    pi.reserve(m); pj.reserve(m); ra.reserve(m);
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             if (std::abs(i - j) < range) continue;
             pi.push_back((uint32_t)i); pj.push_back((uint32_t)j);
-            a.push_back(IF[(size_t)i * n + j]);
+            ra.push_back(rank_matrix[(size_t)i * n + j]);
         }
-    const size_t m = a.size();
-    if (m < 2) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist_batch: range leaves no pairs");
-    std::vector<double> ra;
-    avg_ranks(a, ra);
-    double ma = 0;
-    for (size_t k = 0; k < m; ++k) ma += ra[k];
-    ma /= m;
-    double saa = 0;
-    for (size_t k = 0; k < m; ++k) saa += (ra[k] - ma) * (ra[k] - ma);
     std::vector<double> x((size_t)3 * n), rb(m);
     std::vector<long long> dq(m);
     for (int mdl = 0; mdl < n_models; ++mdl) {

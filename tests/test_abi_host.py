@@ -204,6 +204,40 @@ def test_fast_rounding_equals_printf_semantics(built):
     assert np.allclose(batch, [pipeline.spearman_IF_pdb(IF, xs[k]) for k in range(5)], atol=0, rtol=0)
 
 
+def test_if_ranks_radix_and_symmetric_half_equal_the_plain_definition(built):
+    """The IF side of the Spearman is ranked by a radix sort, and from the upper half when the matrix is symmetric (c3d_host.cpp
+    if_pair_ranks).  Against the oracle and scipy's average ranks: heavy ties, zeros of both signs, negative values, values that
+    differ in the last bit, an asymmetric matrix (falls back to all ordered pairs), and range 0/1/3."""
+    from chromosome3d_amd import pipeline
+    from oracle import oracle as O
+    from scipy.stats import spearmanr
+    rng = np.random.default_rng(5)
+    n = 48
+    x = (rng.normal(size=(n, 3)) * 6).astype(np.float32)
+    xr = np.array([[float("%.3f" % v) for v in row] for row in x.astype(np.float64)])
+    cases = {}
+    a = rng.integers(0, 6, size=(n, n)).astype(np.float64)
+    cases["ties"] = a + a.T
+    b = rng.normal(size=(n, n))
+    b = b + b.T
+    b[rng.random((n, n)) < 0.2] = 0.0
+    b = np.triu(b) + np.triu(b, 1).T
+    b[3, 9] = -0.0; b[9, 3] = 0.0
+    cases["signed_zeros"] = b
+    c = np.full((n, n), 1.0)
+    iu = np.triu_indices(n, 1)
+    c[iu] = 1.0 + rng.integers(0, 4, size=iu[0].size) * np.finfo(np.float64).eps
+    cases["last_bit"] = np.triu(c) + np.triu(c, 1).T
+    cases["asymmetric"] = rng.lognormal(1.0, 1.0, size=(n, n))
+    for name, IF in cases.items():
+        for r in (1, 3):
+            got = pipeline.spearman_IF_pdb(IF, x, r)
+            assert got == pytest.approx(O.spearman_if_dist(IF, xr, r), abs=1e-13), (name, r)
+            i, j = np.nonzero(np.abs(np.subtract.outer(np.arange(n), np.arange(n))) >= r)
+            dd = np.round(np.sqrt(((xr[i] - xr[j]) ** 2).sum(1)), 3)
+            assert abs(got - spearmanr(IF[i, j], dd)[0]) < 1e-10, (name, r)
+
+
 def test_cross_resolution_similarity_reproduces_reference_table(built):
     """output_models/similarity.txt (reference data): the 500 kb model reduced to 1 Mb resolution against
     the 1 Mb model of the same chromosome.  Both bundled chr21 models are fixtures; the reduced model must
