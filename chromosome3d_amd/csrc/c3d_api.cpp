@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -164,6 +166,7 @@ struct c3d_ctx {
     std::vector<int> op_run, op_skip;
     std::vector<c3d::StepRun> prog_runs;
     unsigned* h_tmo = nullptr;             // hipHostMalloc'ed, mapped
+    std::thread preload;                   // loads the code objects of the job's kernels while the caller is busy on the host (c3d_create)
     unsigned* h_tmo_dev = nullptr;         // its device address
 
     long k1_recomputed = 0, k1_patched = 0;   // K1: near-tie elements redone on the host in the reference's order / changed by it
@@ -533,6 +536,7 @@ int run_ops(c3d_ctx* c, size_t nops) {
 
 int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w) {
     if (nops == 0) return C3D_OK;
+    if (c->preload.joinable()) c->preload.join();      // c3d_create's helper: the kernels it loads are wanted now
     if (c->precision == 64 || zero_w) { }                                           // fp64: the per-step path below (k64_step), never the cluster kernel
     else if (c->resident_skip > 0 && c->resident < 1) --c->resident_skip;     // cooling off after an abandoned launch
     else if (nops >= (size_t)c->resident_min_ops && nops < ((size_t)1 << 20)) {
@@ -779,12 +783,28 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
         c3d_destroy(c);
         return fail(C3D_ERR_HIP, "cannot create HIP stream/events");
     }
+    // The first launch from a translation unit loads its code object (2-3 ms for K1's, 9-13 ms for the multi-step kernel's 5 MB) inside the
+    // first job of a process — the reference's usage is one process per matrix.  A helper thread loads the three units a job runs now, once per
+    // process and device, while the caller reads and parses its matrix (first anneal of a process: 31-64 -> 21 ms, steady 12.7;
+    // profiles/r04_first_job_latency.txt, which also records that warming the pageable copy path the same way — 7.5 ms inside K1's upload —
+    // gained nothing: the caller reaches its own first copy before the helper is through and waits for it).  Errors are not reported from
+    // here: what cannot load fails again, loudly, at its first launch.
+    static std::atomic<unsigned> preloaded{0};
+    const unsigned bit = 1u << (device & 31);
+    if (!getenv("C3D_NO_PRELOAD") && !(preloaded.fetch_or(bit) & bit))
+        c->preload = std::thread([device] {
+            if (hipSetDevice(device) != hipSuccess) return;
+            (void)c3d::preload_cluster_unit();     // the largest first; the caller's own first launch (K1) loads c3d_device's meanwhile
+            (void)c3d::preload_score_unit();
+            (void)c3d::preload_device_unit();
+        });
     *out = c;
     return C3D_OK;
 }
 
 extern "C" void c3d_destroy(c3d_ctx* c) {
     if (!c) return;
+    if (c->preload.joinable()) c->preload.join();
     hipSetDevice(c->device);
     for (int g = 0; g < c3d_ctx::kMaxGroups; ++g) if (c->gstream[g]) hipStreamSynchronize(c->gstream[g]);
     drop_graphs(c);

@@ -709,4 +709,9 @@ AnnealIO anneal_io(const DevBuffers& b, int parity) {
     return io;
 }
 
+hipError_t preload_cluster_unit() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_tear16));
+}
+
 }  // namespace c3d

@@ -452,4 +452,9 @@ hipError_t launch_if_to_target(const double* IF, int n, int npad, double alpha, 
     return hipGetLastError();
 }
 
+hipError_t preload_device_unit() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_if_pow_sum));
+}
+
 }  // namespace c3d

@@ -7,6 +7,7 @@
 // :447-485,581-600,716-729 (assessment), :853-857,208-215 (final PDB layout),
 // :93-94 (pseudo-sequence), spearman_IF_pdb.pl:42-70 (metric).
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -63,11 +64,12 @@ extern "C" int c3d_parse_if_file(const char* path, double** IF, int* n_out) {
     double* m = (double*)malloc(sizeof(double) * nn);
     if (!m) return fail(C3D_ERR_NOMEM, "out of memory");
     // Large matrices (110 MB of text at N = 2500) are split at whitespace into one chunk per host thread:
-    // pass 1 counts the tokens of every chunk, pass 2 converts them (strtod: correctly rounded, so the
-    // result does not depend on the split).
+    // pass 1 counts the tokens of every chunk, pass 2 converts them (correctly rounded, so the result does not
+    // depend on the split); a 500 kb chromosome's 1.5 MB takes four threads.
     const char* base = txt.c_str();
     const size_t len = txt.size();
-    unsigned T = len > (size_t)(8u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    unsigned T = len > (size_t)(8u << 20) ? std::min(16u, hw) : len > (size_t)(256u << 10) ? std::min(4u, hw) : 1u;
     std::vector<size_t> cut(T + 1, len);
     cut[0] = 0;
     for (unsigned t = 1; t < T; ++t) {
@@ -103,9 +105,17 @@ extern "C" int c3d_parse_if_file(const char* path, double** IF, int* n_out) {
             while (s < end) {
                 while (s < end && is_ws(*s)) ++s;
                 if (s >= end) break;
-                char* e;
-                const double v = strtod(s, &e);       // stops at the token's end: the text is NUL-terminated
-                if (e == s || (e < base + len && !is_ws(*e))) { bad[t] = 1; return; }
+                // std::from_chars (correctly rounded like strtod, a third of its time); what it does not take whole — a leading '+', hex,
+                // a value out of range — goes to strtod, which stops at the token's end: the text is NUL-terminated
+                double v;
+                const std::from_chars_result fc = std::from_chars(s, end, v);
+                const char* e = fc.ptr;
+                if (fc.ec != std::errc() || (e < base + len && !is_ws(*e))) {
+                    char* se;
+                    v = strtod(s, &se);
+                    e = se;
+                    if (e == s || (e < base + len && !is_ws(*e))) { bad[t] = 1; return; }
+                }
                 m[k++] = v;
                 s = e;
             }

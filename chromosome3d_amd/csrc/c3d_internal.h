@@ -132,6 +132,11 @@ hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPla
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout,
                           unsigned* claim, hipStream_t s);
 // the hand-off's 16-byte atomicity, watched: one producer workgroup, one consumer workgroup on every other CU (c3d_cluster.hip k_tear16)
+// Code objects are loaded on the first use of one of their kernels (one object per translation unit; the multi-step kernel's is 5 MB and takes
+// ~19 ms).  These touch one kernel of their unit so that c3d_create can have them loaded on a helper thread while the caller parses its input.
+hipError_t preload_device_unit();
+hipError_t preload_cluster_unit();
+hipError_t preload_score_unit();
 hipError_t launch_tear16(int num_cus, void* buf, unsigned* stop, unsigned long long* stats, int iters, hipStream_t s);
 // symmetric-tile step for large N (c3d_sym.hip): every pair once.  tiles = sym_tile_list() uploaded, scratch =
 // sym_scratch_floats() floats of device memory (row-side and column-side partial forces of one step).

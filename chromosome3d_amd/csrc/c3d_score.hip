@@ -132,4 +132,9 @@ hipError_t launch_score(const float* xin, const float* tgt, const double* rankA,
     return hipGetLastError();
 }
 
+hipError_t preload_score_unit() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_score_round));
+}
+
 }  // namespace c3d

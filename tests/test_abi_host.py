@@ -281,6 +281,36 @@ def test_threaded_parser_is_exact_and_reports_bad_tokens(built, tmp_path):
         pipeline.parse_if_file(str(tmp_path / "short.txt"))
 
 
+def test_parser_mid_size_split_and_tokens_outside_from_chars(built, tmp_path):
+    """A 500 kb chromosome's ~1.5 MB goes to four threads; numbers are converted by std::from_chars with strtod behind it for what
+    from_chars does not take whole (a leading '+', hex, out-of-range exponents).  Same doubles as Python's float() for every entry,
+    integers, exponents, signed and subnormal values included."""
+    from chromosome3d_amd import C3DError, pipeline
+    n = 300
+    rng = np.random.default_rng(8)
+    a = rng.normal(size=(n, n)) * 10.0 ** rng.integers(-12, 12, size=(n, n))
+    a[rng.random((n, n)) < 0.3] = 0.0
+    k = rng.random((n, n)) < 0.2
+    a[k] = np.round(a[k] % 5000)
+    a[0, :6] = [5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, -0.0, 123456789012345678.0, 0.1]
+    rows = []
+    for row in a:
+        rows.append("\t".join(("%d" % v) if (v == np.round(v) and abs(v) < 1e6 and not np.signbit(v)) else repr(float(v)) for v in row))
+    text = "\n".join(rows) + "\n"
+    assert (256 << 10) < len(text) < (8 << 20)
+    p = tmp_path / "mid.txt"
+    p.write_text(text)
+    got = pipeline.parse_if_file(str(p))
+    assert np.array_equal(got, a) and np.signbit(got[0, 3])
+    small = tmp_path / "odd.txt"
+    small.write_text("+1.5 0x10 1e400\n-1e-400 1E2 .5\n5. inf 7\n")
+    got = pipeline.parse_if_file(str(small))
+    assert np.array_equal(got, np.array([[1.5, 16.0, np.inf], [-0.0, 100.0, 0.5], [5.0, np.inf, 7.0]]))
+    (tmp_path / "bad.txt").write_text(text[: len(text) // 2] + "1.2.3 " + text[len(text) // 2:].split(None, 1)[1])
+    with pytest.raises(C3DError):
+        pipeline.parse_if_file(str(tmp_path / "bad.txt"))
+
+
 def test_residue_names_follow_an_installed_sequence(built, tmp_path):
     """A reference run names residue i after letter i of its fixed pseudo-protein (chromosome3D.pl:93-98; first residues ARG SER
     GLU ASP TRP GLN CYS); its bundled models carry MET everywhere, which stays the default.  With the

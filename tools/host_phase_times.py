@@ -1,0 +1,47 @@
+"""Host-side phases of one chromosome job, timed separately through the C ABI (chr1_500kb, 20 replicas): text parse, K1 with its host
+re-computation of near-tie elements, dist10 read-back, front-half files, start structures, read-back + scoring.  Run on the GPU box:
+python tools/host_phase_times.py [workload]."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from chromosome3d_amd import pipeline
+from chromosome3d_amd.solver import Solver, default_model, default_schedule
+from tests.util import load_if, write_if_text
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "chr1_500kb"
+    IF = load_if(wl)
+    out = {"workload": wl, "n": int(IF.shape[0])}
+    with tempfile.TemporaryDirectory() as td:
+        mat = os.path.join(td, "m.txt")
+        write_if_text(IF, mat)
+        for rep in range(4):
+            if rep in (0, 3):       # pass 3: a second context of the same process (code objects loaded, streams new)
+                s = Solver(0)
+                s.set_model(default_model())
+            ph = {}
+            t = time.perf_counter(); m = pipeline.parse_if_file(mat); ph["parse_ms"] = (time.perf_counter() - t) * 1e3
+            t = time.perf_counter(); s.set_if_matrix(m); ph["set_if_matrix_ms"] = (time.perf_counter() - t) * 1e3
+            ph["k1_recomputed"] = s.stat("k1_recomputed"); ph["k1_patched"] = s.stat("k1_patched")
+            t = time.perf_counter(); d10 = s.dist10(); ph["get_dist10_ms"] = (time.perf_counter() - t) * 1e3
+            t = time.perf_counter()
+            pipeline.write_front_half(d10, td, "a")
+            ph["front_half_files_ms"] = (time.perf_counter() - t) * 1e3
+            s.set_schedule(default_schedule(3000), gtol=1e-2)
+            t = time.perf_counter(); s.init_replicas(20); ph["init_replicas_ms"] = (time.perf_counter() - t) * 1e3
+            t = time.perf_counter(); s.run(); ph["run_ms"] = (time.perf_counter() - t) * 1e3
+            t = time.perf_counter(); x = s.coords(); e = s.energies(); r = s.rank(); ph["coords_energies_rank_ms"] = (time.perf_counter() - t) * 1e3
+            t = time.perf_counter(); sc = s.score(m); ph["score_ms"] = (time.perf_counter() - t) * 1e3
+            out[f"pass{rep}"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ph.items()}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

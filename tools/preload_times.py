@@ -1,0 +1,9 @@
+import ctypes, time, sys, os
+os.environ["C3D_NO_PRELOAD"]="1"
+L=ctypes.CDLL("/root/repo/chromosome3d_amd/_lib/libc3d.so")
+ctx=ctypes.c_void_p()
+t=time.perf_counter(); rc=L.c3d_create(0, ctypes.byref(ctx)); print("create", rc, (time.perf_counter()-t)*1e3)
+order=sys.argv[1].split(",")
+names={"score":"_ZN3c3d18preload_score_unitEv","device":"_ZN3c3d19preload_device_unitEv","cluster":"_ZN3c3d20preload_cluster_unitEv"}
+for o in order:
+    f=getattr(L,names[o]); t=time.perf_counter(); rc=f(); print(o, rc, round((time.perf_counter()-t)*1e3,2),"ms")
