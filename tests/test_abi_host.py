@@ -138,6 +138,47 @@ def test_violation_table_equals_the_references_own(built, tmp_path):
     assert open(v2).read().splitlines()[2:] == ours[2:]
 
 
+def test_violation_rows_equal_printf_formatting(built, tmp_path):
+    """The rows are formatted without printf (c3d_host.cpp put_fixed2 / put_int3).  Against Python's % operator — C's printf — on the
+    arithmetic of chromosome3D.pl:447-485 restated here: random coordinates, coordinates on the 0.0005 grid (distances and deviations on exact
+    .xx5 ties), three-digit and four-digit residue numbers, large distances."""
+    from chromosome3d_amd import pipeline
+    rng = np.random.default_rng(21)
+    n = 1100
+    total = 0
+    for trial, scale in enumerate((2.0, 30.0, 900.0, 5.0)):
+        x = (rng.normal(size=(n, 3)) * scale).astype(np.float32)
+        if trial == 3:
+            x = (np.round(x * 2000) / 2000).astype(np.float32)
+        R = 4000
+        ri = rng.integers(1, n, size=R).astype(np.int32)
+        rj = np.minimum(ri + rng.integers(1, 400, size=R), n).astype(np.int32)
+        rt10 = rng.integers(1, 30000 if scale > 100 else 900, size=R).astype(np.int32)
+        if trial == 3:      # targets that put d - t within a hair of +-0.5 and +-0.2
+            xr0 = np.array([[float("%.3f" % v) for v in row] for row in x.astype(np.float64)])
+            d0 = np.sqrt(((xr0[ri - 1] - xr0[rj - 1]) ** 2).sum(1))
+            rt10 = np.maximum(1, np.round((d0 + rng.choice([-0.5, -0.2, 0.0, 0.2, 0.5], size=R)) * 10)).astype(np.int32)
+        out = tmp_path / f"v{trial}.txt"
+        sat, dev = pipeline.write_violations(x, (ri, rj, rt10), str(out))
+        got = open(out).read().splitlines()[2:]
+        xr = np.array([[float("%.3f" % v) for v in row] for row in x.astype(np.float64)])
+        want, count = [], 0
+        for i, j, t10 in zip(ri, rj, rt10):
+            dx = xr[i - 1] - xr[j - 1]
+            d = float("%.3f" % np.sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]))
+            t = t10 / 10.0
+            flag, deviation = 1, d - t
+            if d < t + 0.5:
+                count += 1; flag = 0; deviation = 0.0
+            if d < t - 0.5:
+                count -= 1; flag = 1; deviation = -(t - d)
+            want.append("%3d\t%.2f\t%.2f # assign45  resid %3d and name ca   resid %3d and name ca  %.2f 0.00 0.00" % (flag, deviation, d, i, j, t))
+        assert sat == count
+        assert got == [r for r in want if r[2] == "1"] + [r for r in want if r[2] == "0"]
+        total += len(got)
+    assert total == 16000
+
+
 def test_violation_writer_error_behaviour(built, tmp_path):
     """Status codes, not crashes: a restraint row outside the model, an unwritable path, null arguments."""
     import ctypes as C
