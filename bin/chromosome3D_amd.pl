@@ -50,6 +50,10 @@ my $solver = $ENV{C3D_SOLVE} || abs_path(dirname(abs_path($0))."/../chromosome3d
 die "ERROR! neither the C3D XS module nor c3d_solve ($solver) is built (python -c 'import __graft_entry__ as g; g.build()')\n" if not $have_xs and not -x $solver;
 
 mkdir $dir_out or die "ERROR! Could not create output directory $dir_out!\n" if not -d $dir_out;
+# C3D_TIMING=1: wall-clock of the driver's phases on stderr (Time::HiRes is core Perl)
+my $t_mark;
+sub tick { return if not $ENV{C3D_TIMING}; require Time::HiRes; my $t = Time::HiRes::time(); printf STDERR "[timing] %-28s %.3f s\n", $_[0], $t - ($t_mark // $^T); $t_mark = $t; }
+tick("perl start, options, XS load");
 print "Start Time : ".(localtime)." [$0]\n";
 print "Input      : $file_if\nOutput Dir : $dir_out\nScaling(K) : $K\nAlpha      : $ALPHA\n";
 print "Effective Conversion Equation is : D = $K * mean(IF^$ALPHA) / IF^$ALPHA\n";
@@ -119,6 +123,7 @@ system("./job.sh > job.log 2>&1");
 die "ERROR! Something went wrong while running c3d_solve! Check job.log!\n".`tail -n 5 job.log` if -f "iam.failed" or not -f "${ID}_${MODELS}.pdb";
 ($restraints) = `cat job.log` =~ /Restraints : (\d+)/;
 }
+tick("(B) build models");
 print "L          : ".first_line_fields("$ID.txt")."\n";
 print "Restraints : ".($restraints // "?")." lines in tbl file\n";
 
@@ -180,6 +185,7 @@ foreach my $pdb ($by_lib ? () : @ordered) {
 	close $vf;
 	printf "%-9s             %-9s                %-25s\n", "$count/$total", (sprintf "%.2f", $sum_dev), basename($pdb, ".pdb");
 }
+tick("(C) satisfaction + violation table");
 print "\n";
 print "removing non-CA ATOM rows and backing up REMARK rows..\n";
 shape_pdb($_, $log) foreach (sort { $e_noe{$b} <=> $e_noe{$a} || $a cmp $b } keys %e_noe);
@@ -191,6 +197,7 @@ foreach my $pdb (sort { $e_noe{$a} <=> $e_noe{$b} || $a cmp $b } keys %e_noe) {
 	rename $pdb, "${ID}_model$rank.pdb" or die $!;
 	last if ++$rank > 5;
 }
+tick("shaping, top five");
 print "\nFinished [$0]: ".(localtime)."\n";
 
 # Output shaping of one model, in place — what the reference's assess_dgsa leaves behind (:813-820): REMARK rows go to
