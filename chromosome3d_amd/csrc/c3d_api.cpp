@@ -534,6 +534,17 @@ int run_ops(c3d_ctx* c, size_t nops) {
     return C3D_OK;
 }
 
+// A stream costs 8.5 ms to make (tools/microbench/hip_init_phases.cpp: the first one of a process 21-160 ms) and the multi-step kernel runs on
+// the context's main stream alone: the streams of replica groups 1.. are made when the per-step path first runs with that many groups.
+int ensure_group_streams(c3d_ctx* c, int G) {
+    for (int g = 1; g < G && g < c3d_ctx::kMaxGroups; ++g) {
+        if (c->gstream[g]) continue;
+        HIP_TRY(hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming));
+    }
+    return C3D_OK;
+}
+
 int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w) {
     if (nops == 0) return C3D_OK;
     if (c->preload.joinable()) c->preload.join();      // c3d_create's helper: the kernels it loads are wanted now
@@ -551,6 +562,7 @@ int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w) {
         if (int rc = ensure_pair_targets(c, dev_model(c))) return rc;
     }
     const int G = active_groups(c);
+    if (int rc = ensure_group_streams(c, G)) return rc;
     // every replica group advances on its own stream (fork from / join into stream 0 around the range): while one
     // group sits in its launch boundary the other computes
     if (G > 1) {
@@ -767,10 +779,7 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
               hipEventCreate(&c->kev0) == hipSuccess && hipEventCreate(&c->kev1) == hipSuccess &&
               hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
-    c->gstream[0] = c->stream;
-    for (int g = 1; ok && g < c3d_ctx::kMaxGroups; ++g)
-        ok = hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess;
+    c->gstream[0] = c->stream;       // the other replica groups' streams: ensure_group_streams, when the per-step path first wants them
     // the word a multi-step launch sets when a workgroup gives up: host memory, read after the stream has drained
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_tmo), 64, hipHostMallocMapped) == hipSuccess;
     if (ok) {
