@@ -220,28 +220,34 @@ extern "C" int c3d_read_tbl(const char* path, int32_t** ri, int32_t** rj, int32_
     std::string txt;
     if (!read_file(path, txt)) return fail(C3D_ERR_IO, std::string("cannot read ") + path);
     std::vector<int32_t> vi, vj, vt;
+    // rows "assign (resid I and name ca) (resid J and name ca) D DMINUS DPLUS": parentheses count as blanks; the tokens are scanned in place
+    // (a std::string per token made this 101 426-row file the slowest part of an assessment)
+    for (char& c : txt) if (c == '(' || c == ')') c = ' ';
+    const char* base = txt.c_str();
     size_t p = 0;
     while (p < txt.size()) {
         size_t e = txt.find('\n', p);
         if (e == std::string::npos) e = txt.size();
-        std::string line = txt.substr(p, e - p);
-        p = e + 1;
-        for (char& c : line) if (c == '(' || c == ')') c = ' ';
-        // tokens: assign resid I and name ca resid J and name ca D DMINUS DPLUS
-        std::vector<std::string> tok;
-        size_t q = 0;
-        while (q < line.size()) {
-            while (q < line.size() && is_ws(line[q])) ++q;
-            size_t b = q;
-            while (q < line.size() && !is_ws(line[q])) ++q;
-            if (q > b) tok.push_back(line.substr(b, q - b));
+        const char* tok[14];
+        int nt = 0;
+        size_t q = p;
+        while (q < e) {
+            while (q < e && is_ws(base[q])) ++q;
+            const size_t b0 = q;
+            while (q < e && !is_ws(base[q])) ++q;
+            if (q > b0) { if (nt < 14) tok[nt] = base + b0; ++nt; }
         }
-        if (tok.empty()) continue;
-        if (tok[0].compare(0, 6, "assign") != 0) return fail(C3D_ERR_IO, std::string("contact.tbl: unexpected row: ") + line);
-        if (tok.size() < 14) return fail(C3D_ERR_IO, std::string("contact.tbl: short row: ") + line);
-        vi.push_back(atoi(tok[2].c_str()));
-        vj.push_back(atoi(tok[7].c_str()));
-        vt.push_back((int32_t)llround(atof(tok[11].c_str()) * 10.0));
+        const std::string line = nt == 0 || (nt >= 14 && strncmp(tok[0], "assign", 6) == 0) ? std::string() : txt.substr(p, e - p);
+        p = e + 1;
+        if (nt == 0) continue;
+        if (strncmp(tok[0], "assign", 6) != 0) return fail(C3D_ERR_IO, std::string("contact.tbl: unexpected row: ") + line);
+        if (nt < 14) return fail(C3D_ERR_IO, std::string("contact.tbl: short row: ") + line);
+        vi.push_back(atoi(tok[2]));                  // (atoi / strtod stop at the token's end: a blank, or the text's final NUL)
+        vj.push_back(atoi(tok[7]));
+        double tv;
+        const std::from_chars_result fc = std::from_chars(tok[11], base + e, tv);
+        if (fc.ec != std::errc() || (fc.ptr < base + e && !is_ws(*fc.ptr))) tv = strtod(tok[11], nullptr);
+        vt.push_back((int32_t)llround(tv * 10.0));
     }
     const size_t r = vi.size();
     *ri = (int32_t*)malloc(sizeof(int32_t) * (r ? r : 1));
