@@ -756,6 +756,13 @@ extern "C" int c3d_default_schedule(c3d_stage* st, int cap, int min_steps) {
     return (int)v.size();
 }
 
+static std::atomic<int> g_preload{1};
+extern "C" int c3d_set_process_option(const char* key, double value) {
+    if (!key) return fail(C3D_ERR_INVALID, "c3d_set_process_option: null key");
+    if (!strcmp(key, "preload")) { g_preload.store(value != 0); return C3D_OK; }
+    return fail(C3D_ERR_INVALID, std::string("c3d_set_process_option: unknown key ") + key);
+}
+
 extern "C" int c3d_create(int device, c3d_ctx** out) {
     if (!out) return fail(C3D_ERR_INVALID, "c3d_create: null out");
     int ndev = 0;
@@ -800,7 +807,7 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     // here: what cannot load fails again, loudly, at its first launch.
     static std::atomic<unsigned> preloaded{0};
     const unsigned bit = 1u << (device & 31);
-    if (!getenv("C3D_NO_PRELOAD") && !(preloaded.fetch_or(bit) & bit))
+    if (g_preload.load() && !(preloaded.fetch_or(bit) & bit))
         c->preload = std::thread([device] {
             if (hipSetDevice(device) != hipSuccess) return;
             (void)c3d::preload_cluster_unit();     // the largest first; the caller's own first launch (K1) loads c3d_device's meanwhile

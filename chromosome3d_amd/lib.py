@@ -56,6 +56,7 @@ SIGNATURES = {
     "c3d_set_model": (_i, [_vp, C.POINTER(Model)]),
     "c3d_set_schedule": (_i, [_vp, C.POINTER(Stage), _i, C.POINTER(FireParams), _f, _i]),
     "c3d_set_option": (_i, [_vp, C.c_char_p, _d]),
+    "c3d_set_process_option": (_i, [C.c_char_p, _d]),
     "c3d_init_replicas": (_i, [_vp, _i, C.c_uint64, C.c_uint32]),
     "c3d_embed_replicas": (_i, [_vp, _i]),
     "c3d_set_coords": (_i, [_vp, _fp]),

@@ -841,3 +841,42 @@ def test_packed_pair_term_has_the_scalar_forms_bits(solver, cid):
             assert np.array_equal(Fs, Fp), np.abs(Fs - Fp).max()
     finally:
         solver.set_option("eval_rows_per_wave", 4)
+
+
+def test_first_job_helper_and_lazy_group_streams_change_no_bit(built):
+    """c3d_create's helper thread (code objects loaded while the caller parses; include/c3d.h c3d_set_process_option "preload") and the
+    replica-group streams made on first use are latency measures: a fresh process with the helper and one without end a job — K1, 300
+    steps of the default schedule through the multi-step kernel, then 40 steps on the per-step path with two and three replica groups —
+    in the same coordinates, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+from chromosome3d_amd import lib
+from chromosome3d_amd.solver import Solver, default_model, default_schedule
+from tests.util import load_if
+if sys.argv[1] == "0":
+    lib.check(lib.load().c3d_set_process_option(b"preload", 0.0))
+s = Solver(0)
+s.set_model(default_model())
+s.set_if_matrix(load_if("chr20_1mb"))
+s.set_schedule(default_schedule(3000))
+s.init_replicas(6, seed=5)
+s.run_steps(300)
+h = [hashlib.md5(np.ascontiguousarray(s.coords()).tobytes()).hexdigest(), str(int(s.stat("cluster_launches")))]
+for g in (2, 3):
+    s.set_option("resident", 0)
+    s.set_option("replica_groups", g)
+    s.run_steps(40)
+    h.append(hashlib.md5(np.ascontiguousarray(s.coords()).tobytes()).hexdigest())
+print("HASH", " ".join(h))
+''' % root
+    out = []
+    for flag in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", code, flag], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out.append([l for l in p.stdout.splitlines() if l.startswith("HASH")][-1].split()[1:])
+    assert out[0] == out[1] and int(out[0][1]) >= 1 and len(set(out[0][i] for i in (0, 2, 3))) == 3

@@ -1,6 +1,6 @@
 """Host-side phases of one chromosome job, timed separately through the C ABI (chr1_500kb, 20 replicas): text parse, K1 with its host
 re-computation of near-tie elements, dist10 read-back, front-half files, start structures, read-back + scoring.  Run on the GPU box:
-python tools/host_phase_times.py [workload]."""
+python tools/host_phase_times.py [workload] [--no-preload]."""
 import json
 import os
 import sys
@@ -16,7 +16,11 @@ from tests.util import load_if, write_if_text
 
 
 def main():
-    wl = sys.argv[1] if len(sys.argv) > 1 else "chr1_500kb"
+    args = [a for a in sys.argv[1:] if a != "--no-preload"]
+    wl = args[0] if args else "chr1_500kb"
+    if "--no-preload" in sys.argv:
+        from chromosome3d_amd import lib
+        lib.check(lib.load().c3d_set_process_option(b"preload", 0.0))
     IF = load_if(wl)
     out = {"workload": wl, "n": int(IF.shape[0])}
     with tempfile.TemporaryDirectory() as td:
