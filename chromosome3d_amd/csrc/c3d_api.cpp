@@ -166,6 +166,8 @@ struct c3d_ctx {
     std::vector<int> op_run, op_skip;
     std::vector<c3d::StepRun> prog_runs;
     unsigned* h_tmo = nullptr;             // hipHostMalloc'ed, mapped
+    void* h_stage = nullptr;               // pinned host staging of the read-backs (ensure_stage)
+    size_t h_stage_bytes = 0;
     std::thread preload;                   // loads the code objects of the job's kernels while the caller is busy on the host (c3d_create)
     unsigned* h_tmo_dev = nullptr;         // its device address
 
@@ -348,9 +350,9 @@ void pack(const c3d_ctx* c, const float* aos, std::vector<float>& soa, bool pad_
         }
     }
 }
-void unpack(const c3d_ctx* c, const std::vector<float>& soa, float* aos) {
+void unpack(const c3d_ctx* c, const float* soa, float* aos) {
     for (int r = 0; r < c->nrep; ++r) {
-        const float* base = soa.data() + c->rep_floats * r;
+        const float* base = soa + c->rep_floats * r;
         for (int comp = 0; comp < 3; ++comp)
             for (int i = 0; i < c->n; ++i) aos[((size_t)r * c->n + i) * 3 + comp] = base[(size_t)comp * c->npad + i];
     }
@@ -655,12 +657,29 @@ int end_timing(c3d_ctx* c) {
     return C3D_OK;
 }
 
+// Read-backs (exit test of the minimiser, coordinates, energies, scoring sums) land in a pinned buffer the context owns: the runtime does not
+// have to pin a pageable destination for every copy, and what a copy costs does not depend on where the allocator put the destination.
+int ensure_stage(c3d_ctx* c, size_t bytes) {
+    if (bytes <= c->h_stage_bytes) return C3D_OK;
+    if (c->h_stage) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_bytes = 0; }
+    const size_t cap = std::max<size_t>(bytes, (size_t)64 << 10);
+    HIP_TRY(hipHostMalloc(&c->h_stage, cap, hipHostMallocDefault));
+    c->h_stage_bytes = cap;
+    return C3D_OK;
+}
+// device -> pinned staging, synchronised; the caller reads c->h_stage
+int read_back(c3d_ctx* c, const void* dev, size_t bytes) {
+    if (int rc = ensure_stage(c, bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_stage, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C3D_OK;
+}
+
 // max over replicas of the RMS force from the FIRE partial sums of the current parity
 int max_rms_force(c3d_ctx* c, double* out) {
     const int nparts = c->ntiles;
-    std::vector<float> h((size_t)c->nrep * nparts * 4);
-    HIP_TRY(hipMemcpyAsync(h.data(), c->buf.P[c->parity], sizeof(float) * h.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = read_back(c, c->buf.P[c->parity], sizeof(float) * (size_t)c->nrep * nparts * 4)) return rc;
+    const float* h = static_cast<const float*>(c->h_stage);
     double worst = 0;
     for (int r = 0; r < c->nrep; ++r) {
         double ff = 0;
@@ -674,11 +693,11 @@ int max_rms_force(c3d_ctx* c, double* out) {
 
 // are the last step's per-tile sums (functions of every velocity / force component) all finite?
 int partials_finite(c3d_ctx* c, bool* ok) {
-    std::vector<float> h((size_t)c->nrep * c->ntiles * 4);
-    HIP_TRY(hipMemcpyAsync(h.data(), c->buf.P[c->parity], sizeof(float) * h.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t cnt = (size_t)c->nrep * c->ntiles * 4;
+    if (int rc = read_back(c, c->buf.P[c->parity], sizeof(float) * cnt)) return rc;
+    const float* h = static_cast<const float*>(c->h_stage);
     *ok = true;
-    for (float v : h) if (!std::isfinite(v)) { *ok = false; break; }
+    for (size_t k = 0; k < cnt; ++k) if (!std::isfinite(h[k])) { *ok = false; break; }
     return C3D_OK;
 }
 
@@ -828,6 +847,7 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
     dev_free(c->buf.tgt); dev_free(c->buf.tgs2);
     dev_free(c->d_prog); dev_free(c->d_claim);
     if (c->h_tmo) (void)hipHostFree(c->h_tmo);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->kev0) hipEventDestroy(c->kev0);
@@ -1148,6 +1168,10 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
         HIP_TRY(hipMemsetAsync(c->buf.S[k], 0, sizeof(c3d::FireState) * nrep, c->stream));
     }
     HIP_TRY(hipMemsetAsync(c->d_feval, 0, sizeof(float) * nf, c->stream));
+    // The seven fills above are waited for here.  Left in flight behind the call, they made the first synchronisation after the first multi-step
+    // launch of a process — the minimiser's first exit test — take 8 ms instead of 0.02 (first anneal 21 against 12.7 ms; measured with
+    // tools/host_phase_times.py, profiles/r04_first_job_latency.txt; the mechanism inside the runtime was not pursued).
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->pc = 0; c->parity = 0; c->steps_done = 0;
     if (c->precision == 64) {
         if (c->h_dist10.empty()) return fail(C3D_ERR_INVALID, "precision 64 needs targets built from an IF matrix (integer tenths)");
@@ -1228,11 +1252,8 @@ extern "C" int c3d_set_coords(c3d_ctx* c, const float* xyz) {
     return C3D_OK;
 }
 static int get_soa(c3d_ctx* c, const float* dev, float* aos) {
-    std::vector<float> soa(c->rep_floats * c->nrep);
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpyAsync(soa.data(), dev, sizeof(float) * soa.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    unpack(c, soa, aos);
+    if (int rc = read_back(c, dev, sizeof(float) * c->rep_floats * c->nrep)) return rc;
+    unpack(c, static_cast<const float*>(c->h_stage), aos);
     return C3D_OK;
 }
 extern "C" int c3d_get_coords(c3d_ctx* c, float* xyz) {
@@ -1403,9 +1424,8 @@ extern "C" int c3d_eval(c3d_ctx* c, float w_all, float w_vdw, float repel_s, flo
         const double rr = (double)repel_s * (double)c->model.r0_rep;
         hipError_t err = c3d::launch_energy(m, p, c->buf, c->parity, c->model.s_noe, c->model.k_rep, rr * rr, c->stream);
         if (err != hipSuccess) return fail(C3D_ERR_HIP, std::string("energy launch: ") + hipGetErrorString(err));
-        std::vector<double> h((size_t)4 * c->nrep);
-        HIP_TRY(hipMemcpyAsync(h.data(), c->buf.E, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (int rc = read_back(c, c->buf.E, sizeof(double) * 4 * (size_t)c->nrep)) return rc;
+        const double* h = static_cast<const double*>(c->h_stage);
         for (int r = 0; r < c->nrep; ++r) for (int k = 0; k < 3; ++k) e[3 * r + k] = h[4 * r + k];
     }
     return C3D_OK;
@@ -1448,16 +1468,19 @@ extern "C" int c3d_score_replicas(c3d_ctx* c, const double* IF, int range, int32
     hipError_t e = c3d::launch_score(c->buf.X[c->parity], c->buf.tgt, d_rank.p, n, c->npad, nrep, range, c->model.min_sep, nbins, ma,
                                      mb, 0.5, d_xr.p, d_hist.p, d_below.p, d_part.p, d_ovf.p, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("score launch: ") + hipGetErrorString(e));
-    std::vector<double> part((size_t)4 * n * nrep);
-    int ovf = 0;
-    HIP_TRY(hipMemcpyAsync(part.data(), d_part.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&ovf, d_ovf.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    const size_t part_bytes = sizeof(double) * 4 * (size_t)n * nrep;
+    if (int rc = ensure_stage(c, part_bytes + 64)) return rc;
+    char* const stage = static_cast<char*>(c->h_stage);
+    HIP_TRY(hipMemcpyAsync(stage, d_part.p, part_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(stage + part_bytes, d_ovf.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const double* const part = reinterpret_cast<const double*>(stage);
+    const int ovf = *reinterpret_cast<const int*>(stage + part_bytes);
     if (ovf) return fail(C3D_ERR_INVALID, "c3d_score_replicas: a pair distance exceeds 262 A (device histogram range)");
     for (int r = 0; r < nrep; ++r) {
         double sab = 0, sbb = 0, sat = 0, dev = 0;
         for (int i = 0; i < n; ++i) {    // fixed order: deterministic
-            const double* q = part.data() + ((size_t)r * n + i) * 4;
+            const double* q = part + ((size_t)r * n + i) * 4;
             sab += q[0]; sbb += q[1]; sat += q[2]; dev += q[3];
         }
         if (satisfied) satisfied[r] = (int32_t)llround(sat);

@@ -16,7 +16,7 @@ from tests.util import load_if, write_if_text
 
 
 def main():
-    args = [a for a in sys.argv[1:] if a != "--no-preload"]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
     wl = args[0] if args else "chr1_500kb"
     if "--no-preload" in sys.argv:
         from chromosome3d_amd import lib
@@ -40,6 +40,8 @@ def main():
             ph["front_half_files_ms"] = (time.perf_counter() - t) * 1e3
             s.set_schedule(default_schedule(3000), gtol=1e-2)
             t = time.perf_counter(); s.init_replicas(20); ph["init_replicas_ms"] = (time.perf_counter() - t) * 1e3
+            if "--coords-first" in sys.argv:
+                t = time.perf_counter(); s.coords(); ph["coords_before_run_ms"] = (time.perf_counter() - t) * 1e3
             t = time.perf_counter(); s.run(); ph["run_ms"] = (time.perf_counter() - t) * 1e3
             t = time.perf_counter(); x = s.coords(); e = s.energies(); r = s.rank(); ph["coords_energies_rank_ms"] = (time.perf_counter() - t) * 1e3
             t = time.perf_counter(); sc = s.score(m); ph["score_ms"] = (time.perf_counter() - t) * 1e3
