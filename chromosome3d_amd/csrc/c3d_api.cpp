@@ -820,10 +820,10 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     }
     // The first launch from a translation unit loads its code object (2-3 ms for K1's, 9-13 ms for the multi-step kernel's 5 MB) inside the
     // first job of a process — the reference's usage is one process per matrix.  A helper thread loads the three units a job runs now, once per
-    // process and device, while the caller reads and parses its matrix (first anneal of a process: 31-64 -> 21 ms, steady 12.7;
-    // profiles/r04_first_job_latency.txt, which also records that warming the pageable copy path the same way — 7.5 ms inside K1's upload —
-    // gained nothing: the caller reaches its own first copy before the helper is through and waits for it).  Errors are not reported from
-    // here: what cannot load fails again, loudly, at its first launch.
+    // process and device, while the caller reads and parses its matrix (first anneal of a process: 31-64 -> 21 ms; 12.8, the steady figure,
+    // with c3d_init_replicas waiting for its fills; profiles/r04_first_job_latency.txt, which also records that warming the copy path the
+    // same way — the first copy of a process, 7.5 ms inside K1's upload — gained nothing: the caller reaches its own first copy before the
+    // helper is through and waits for it).  Errors are not reported from here: what cannot load fails again, loudly, at its first launch.
     static std::atomic<unsigned> preloaded{0};
     const unsigned bit = 1u << (device & 31);
     if (g_preload.load() && !(preloaded.fetch_or(bit) & bit))
