@@ -525,6 +525,13 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     else role_loop(std::integral_constant<int, 2>{});
 }
 
+// Built as six translation units (Makefile): this file once with -DC3D_CLUSTER_SPLIT — planner, dispatch, k_tear16, no instantiation of
+// k_cluster — and once per device potential with -DC3D_CLUSTER_POT=0..4, each carrying that potential's geometries alone.  The 5 MB code
+// object of all 200 instantiations took 9-13 ms to load at the first launch of a process and over two minutes to compile; a job loads
+// the unit of its potential only (the shipped one: 86 kernels).  Without either macro the file is the single unit it used to be
+// (tools/stamps/build.sh).
+constexpr bool cluster_late_ok(int pot, int rpw, int nb, int wl) { return pot >= 3 && rpw * (4 * (nb - 1) + wl) >= 6; }
+#ifndef C3D_CLUSTER_POT
 #ifdef C3D_STAMPS
 hipError_t read_cluster_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cstamps), sizeof(unsigned long long) * 64 * 8); }
 hipError_t read_cluster_pstamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * 8); }
@@ -573,7 +580,6 @@ hipError_t launch_tear16(int num_cus, void* buf, unsigned* stop, unsigned long l
 // Tile sums late (H0 fetches them after B1, LATE = true) where the pair loop of a compute wave — rows x column slots — outlasts
 // H0's later scalars; measured on 13 problems, N = 76 .. 455 (profiles/r03_late_tiles_ab.txt).  Shipped potential only: every
 // (geometry, LATE) pair is one more kernel to compile.
-constexpr bool cluster_late_ok(int pot, int rpw, int nb, int wl) { return pot >= 3 && rpw * (4 * (nb - 1) + wl) >= 6; }
 
 bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, int forced_late, ClusterPlan* plan) {
     // the placement arithmetic (replica r on XCD r % 8, XCC_ID & 7) is written for the 8 XCDs of an unpartitioned MI355X:
@@ -637,6 +643,8 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
 // two parities x replicas x (one 16-byte unit per row + two per 8-row tile)
 size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl) { (void)pl; return (size_t)2 * m.nrep_g * (m.npad + m.npad / 4) * 16; }
 
+#endif  // !C3D_CLUSTER_POT
+
 template <int POT, int RPW, int NB, int WL, bool LATE>
 static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                              const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
@@ -689,17 +697,40 @@ static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const Clust
     return hipErrorInvalidValue;
 }
 
+#define C3D_CL_CAT2(a, b) a##b
+#define C3D_CL_CAT(a, b) C3D_CL_CAT2(a, b)
+#if defined(C3D_CLUSTER_POT)
+// one potential's unit: its dispatch and one of its kernels to touch (preload)
+hipError_t C3D_CL_CAT(launch_cluster_pot, C3D_CLUSTER_POT)(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
+                          const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
+                          hipStream_t s) {
+    return cluster_geom<C3D_CLUSTER_POT>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
+}
+hipError_t C3D_CL_CAT(preload_cluster_pot, C3D_CLUSTER_POT)() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_cluster<C3D_CLUSTER_POT, 2, 2, 4, false>));
+}
+#else
+#if defined(C3D_CLUSTER_SPLIT)
+#define C3D_CL_DECL(P) hipError_t launch_cluster_pot##P(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec, const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim, hipStream_t s); hipError_t preload_cluster_pot##P();
+C3D_CL_DECL(0) C3D_CL_DECL(1) C3D_CL_DECL(2) C3D_CL_DECL(3) C3D_CL_DECL(4)
+#undef C3D_CL_DECL
+#define C3D_CL_POT(P) launch_cluster_pot##P(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s)
+#else
+#define C3D_CL_POT(P) cluster_geom<P>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s)
+#endif
 hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                           hipStream_t s) {
     switch (m.noe_pot) {
-        case 0: return cluster_geom<0>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
-        case 1: return cluster_geom<1>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
-        case 3: return cluster_geom<3>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
-        case 4: return cluster_geom<4>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
-        default: return cluster_geom<2>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
+        case 0: return C3D_CL_POT(0);
+        case 1: return C3D_CL_POT(1);
+        case 3: return C3D_CL_POT(3);
+        case 4: return C3D_CL_POT(4);
+        default: return C3D_CL_POT(2);
     }
 }
+#undef C3D_CL_POT
 
 AnnealIO anneal_io(const DevBuffers& b, int parity) {
     const int q = parity ^ 1;
@@ -709,9 +740,15 @@ AnnealIO anneal_io(const DevBuffers& b, int parity) {
     return io;
 }
 
+// the unit of the shipped potential (device potential 4): what a default job launches
 hipError_t preload_cluster_unit() {
+#if defined(C3D_CLUSTER_SPLIT)
+    return preload_cluster_pot4();
+#else
     hipFuncAttributes a;
     return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_tear16));
+#endif
 }
+#endif  // C3D_CLUSTER_POT
 
 }  // namespace c3d
