@@ -818,7 +818,7 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
         c3d_destroy(c);
         return fail(C3D_ERR_HIP, "cannot create HIP stream/events");
     }
-    // The first launch from a translation unit loads its code object (2-3 ms for K1's, 9-13 ms for the multi-step kernel's 5 MB) inside the
+    // The first launch from a translation unit loads its code object (2-3 ms for K1's, 3 ms for the shipped potential's multi-step kernels — 9-13 ms while all five potentials shared one unit) inside the
     // first job of a process — the reference's usage is one process per matrix.  A helper thread loads the three units a job runs now, once per
     // process and device, while the caller reads and parses its matrix (first anneal of a process: 31-64 -> 21 ms; 12.8, the steady figure,
     // with c3d_init_replicas waiting for its fills; profiles/r04_first_job_latency.txt, which also records that warming the copy path the

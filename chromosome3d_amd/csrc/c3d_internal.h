@@ -132,8 +132,9 @@ hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPla
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout,
                           unsigned* claim, hipStream_t s);
 // the hand-off's 16-byte atomicity, watched: one producer workgroup, one consumer workgroup on every other CU (c3d_cluster.hip k_tear16)
-// Code objects are loaded on the first use of one of their kernels (one object per translation unit; the multi-step kernel's is 5 MB and takes
-// ~19 ms).  These touch one kernel of their unit so that c3d_create can have them loaded on a helper thread while the caller parses its input.
+// Code objects are loaded on the first use of one of their kernels, one object per translation unit (K1's 2-3 ms, the shipped potential's
+// multi-step kernels 3 ms, scoring 0.3 ms).  These touch one kernel of their unit so that c3d_create can have them loaded on a helper thread
+// while the caller parses its input.
 hipError_t preload_device_unit();
 hipError_t preload_cluster_unit();
 hipError_t preload_score_unit();

@@ -150,8 +150,8 @@ int c3d_set_option(c3d_ctx* ctx, const char* key, double value);
 /* Process-wide switches, to be set before the first c3d_create (no environment variable is read by the library):
  *   preload         1 (default) / 0: the first c3d_create of a process for a device starts a helper thread that loads the code objects of the
  *                   kernels a job runs (K1, the multi-step kernel, scoring) while the caller reads and parses its matrix; without it they load
- *                   at their first launch, inside the first job (the multi-step kernel's 5 MB object alone takes 9-13 ms of a 12.7 ms
- *                   anneal: profiles/r04_first_job_latency.txt).  Results are untouched by it (measurement knob). */
+ *                   at their first launch, inside the first job (2-3 ms each for K1's and the multi-step kernel's unit:
+ *                   profiles/r04_first_job_latency.txt).  Results are untouched by it (measurement knob). */
 int c3d_set_process_option(const char* key, double value);
 
 /* --- replicas ----------------------------------------------------------------------- */
