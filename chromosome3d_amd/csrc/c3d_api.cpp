@@ -126,6 +126,7 @@ struct c3d_ctx {
     c3d::DevBuffers buf{};
     int eval_rpw = 4;                      // option "eval_rows_per_wave": 4 = scalar pair term in the forces hook, 2 = the packed one, -2 = scalar at two rows per wave
     bool pair_targets = true;              // option "pair_targets": the per-step kernel's resident row-pair constants (measurement knob)
+    bool wide_tiles = true;                // option "wide_tiles": beyond the multi-step kernel's reach, 16 rows a workgroup and 4 a wave (measurement knob)
     float* d_feval = nullptr;
     size_t rep_floats = 0;           // 3*npad per replica
     bool have_targets = false, have_replicas = false;
@@ -389,6 +390,12 @@ int build_targets64(c3d_ctx* c) {
 
 // Per-step kernel beyond the cluster kernel's reach (no narrow column block: every n > 1024), device potential 4: the resident per-pair
 // constants of row pairs (DevModel::tgs2), built on first use after the targets or the model changed
+// the per-step kernel's wide form: the shipped potential's clamp forms on a problem beyond the multi-step kernel's reach whose columns fill
+// whole blocks (every n > 1024 the library pads that way), at the default two rows per wave of the narrow form it replaces
+bool wide_step(const c3d_ctx* c, const c3d::DevModel& m, bool general) {
+    return c->wide_tiles && c->pair_targets && !general && m.noe_pot == 4 && m.wl == 4 && m.nleft == 0 && c->npad > 1024 && c->rpw == 2;
+}
+
 int ensure_pair_targets(c3d_ctx* c, const c3d::DevModel& m) {
     if (c->buf.tgs2 || !c->pair_targets || m.noe_pot != 4 || m.wl != 4 || m.nleft != 0 || c->npad <= 1024 || c->rpw != 2 || !c->buf.tgt) return C3D_OK;
     HIP_TRY(hipMalloc(&c->buf.tgs2, sizeof(float) * c3d::pair_targets_floats(c->n, c->npad)));
@@ -413,7 +420,7 @@ int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
     }
     c->last_general = general_step(m, op.p);
     hipError_t e = use_sym(c) ? c3d::launch_step_sym(m, op.p, dev_fire(c), c->buf, par, c->d_sym_tiles, c->d_sym_scratch, c->gstream[g])
-                              : c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, c->last_general, c->gstream[g]);
+                              : c3d::launch_step(m, op.p, dev_fire(c), c->buf, par, c->last_general, wide_step(c, m, c->last_general), c->gstream[g]);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("step launch: ") + hipGetErrorString(e));
     return C3D_OK;
 }
@@ -918,6 +925,7 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
         return C3D_OK;
     }
     if (!strcmp(key, "pair_targets")) { c->pair_targets = value != 0; dev_free(c->buf.tgs2); drop_graphs(c); return C3D_OK; }
+    if (!strcmp(key, "wide_tiles")) { c->wide_tiles = value != 0; drop_graphs(c); return C3D_OK; }
     if (!strcmp(key, "symmetric")) {       // takes effect at the next c3d_init_replicas with a new replica count / matrix
         c->sym = value > 0;
         free_replica_buffers(c);
@@ -1405,7 +1413,8 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %d, %s>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, m.wl, c->cl_plan.late_tiles ? "true" : "false");
     else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);
     else if (c->precision == 64) snprintf(buf, sizeof(buf), "c3d::k64_step<%d, %s>", m.noe_pot, general_tail(m) ? "true" : "false");
-    else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d, %s>", m.noe_pot, gen, m.rpw, (m.wl == 4 && m.nleft == 0) ? "false" : "true");
+    else if (wide_step(c, m, general_tail(m) || c->last_general)) snprintf(buf, sizeof(buf), "c3d::k_step<4, false, 4, false, 16, true>");
+    else snprintf(buf, sizeof(buf), "c3d::k_step<%d, %s, %d, %s, 8, false>", m.noe_pot, gen, m.rpw, (m.wl == 4 && m.nleft == 0) ? "false" : "true");
     return buf;
 }
 

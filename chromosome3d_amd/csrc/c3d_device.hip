@@ -59,14 +59,19 @@ inline dim3 grid_blocks(const DevModel& m) { return dim3(8, m.nrep_g, (m.ntiles 
 //   4. lanes 0..RPW-1 finish one row each; tile partial sums through LDS
 // ---------------------------------------------------------------------------------------------
 
-template <int POT, bool GEN, int RPW, bool NC>
-__global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
+// TR = rows of a workgroup: kTileRows, or (WIDE) two 8-row tiles with four rows per wave in the packed form — problems beyond the multi-step
+// kernel's reach (n > 1024), where a wave's fixed work per step (sums, scalars, chain terms, row update: ~500 instructions) was a third of
+// its instructions at two rows per wave; the tile sums keep their 8-row tree and their place in P
+template <int POT, bool GEN, int RPW, bool NC, int TR = kTileRows, bool WIDE = false>
+__global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : 1))) void k_step(
     const float* __restrict__ pin, const float* __restrict__ xin, const float* __restrict__ tgt,
     const float* __restrict__ vin, const float* __restrict__ vinit, const FireState* __restrict__ sin,
     float* __restrict__ xout, float* __restrict__ vout, float* __restrict__ pout, FireState* __restrict__ sout,
     const DevModel m, const DevStep p, const DevFire fp) {
-    constexpr int WAVES = kTileRows / RPW;
+    constexpr int WAVES = TR / RPW;
     constexpr int BLOCK = 64 * WAVES;
+    constexpr int TILES = TR / kTileRows;       // 8-row tiles of this workgroup
+    static_assert(TR % kTileRows == 0 && TILES >= 1 && TILES <= 2, "a workgroup owns one or two 8-row tiles");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     C3D_STAMP(6);      // before any kernel argument beyond the preloaded ones is needed
     {   // The 280-byte kernarg block spans five 64-byte lines and the scalar cache is cold at every launch: the
@@ -82,14 +87,16 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
                      : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(ka) : "memory");
     }
     int tile, rep;
-    if (!block_to_tile(m, tile, rep)) return;
+    if (!block_to_tile(m, tile, rep)) return;   // (tile = the workgroup's number among those of its replica)
+    tile *= TILES;                              // its first 8-row tile
+    if (tile >= m.ntiles) return;
     C3D_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npad = m.npad;
     float* xs = smem;
     float* ys = smem + npad;
     float* zs = smem + 2 * npad;
-    float* rowq = smem + 3 * npad;              // [kTileRows][4] per-row contributions to the replica sums
+    float* rowq = smem + 3 * npad;              // [TR][4] per-row contributions to the replica sums
     const size_t roff = (size_t)rep * 3 * npad;
     const int row0 = tile * kTileRows + wave * RPW;
     const int row = row0 + lane;                // the row this lane finishes (lanes < RPW only)
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
 
     // ---- 3. K2: pair forces for this wave's rows ---------------------------------------------
     float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
-    if (p.kind != 4) tile_forces<POT, GEN, RPW, NC>(m, p, tgt, xs, ys, zs, row0, lane, tv, Fx, Fy, Fz);
+    if (p.kind != 4) tile_forces<POT, GEN, RPW, NC, true, WIDE>(m, p, tgt, xs, ys, zs, row0, lane, tv, Fx, Fy, Fz);
 
     C3D_STAMP(4);
     // ---- 4. epilogue: lanes 0..RPW-1 finish one row each --------------------------------------
@@ -153,7 +160,8 @@ __global__ __launch_bounds__(64 * kTileRows / RPW) void k_step(
     // tile partial sums: the fixed tree of tile_sum8 over the eight rows (deterministic, the cluster kernel's order)
     if (fin_lane) reinterpret_cast<float4*>(rowq)[row - tile * kTileRows] = q;
     __syncthreads();
-    if (tid == 0) reinterpret_cast<float4*>(pout)[(size_t)rep * m.ntiles + tile] = tile_sum8(reinterpret_cast<const float4*>(rowq));
+    if (tid < TILES && tile + tid < m.ntiles)
+        reinterpret_cast<float4*>(pout)[(size_t)rep * m.ntiles + tile + tid] = tile_sum8(reinterpret_cast<const float4*>(rowq) + kTileRows * tid);
     C3D_STAMP(5);
 }
 
@@ -182,14 +190,23 @@ hipError_t launch_pair_targets(const DevModel& m, const float* tgt, float* tgs2,
     return hipGetLastError();
 }
 
-static size_t step_lds_bytes(const DevModel& m) { return sizeof(float) * ((size_t)3 * m.npad + 4 * kTileRows); }   // xyz + rowq
+static size_t step_lds_bytes(const DevModel& m, int tile_rows = kTileRows) { return sizeof(float) * ((size_t)3 * m.npad + 4 * tile_rows); }   // xyz + rowq
 
 template <int POT, bool GEN, int RPW>
-static hipError_t launch_step_r(const DevModel& m0, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
+static hipError_t launch_step_r(const DevModel& m0, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par, bool wide,
                                 hipStream_t s) {
     const int q = par ^ 1;
     DevModel m = m0;
-    m.tgs2 = (POT == 4 && !GEN && RPW == 2 && m.wl == 4 && m.nleft == 0) ? b.tgs2 : nullptr;      // (the one kernel that reads it)
+    m.tgs2 = (POT == 4 && !GEN && RPW == 2 && m.wl == 4 && m.nleft == 0) ? b.tgs2 : nullptr;      // (the kernels that read it)
+    if constexpr (POT == 4 && !GEN && RPW == 2) {
+        if (wide && m.wl == 4 && m.nleft == 0 && m.tgs2) {      // 16 rows a workgroup, four a wave (two packed row pairs; resident pair targets)
+            constexpr int TR = 2 * kTileRows;
+            const int nwg = (m.ntiles + 1) / 2;
+            hipLaunchKernelGGL((k_step<4, false, 4, false, TR, true>), dim3(8, m.nrep_g, (nwg + 7) / 8), dim3(64 * TR / 4), step_lds_bytes(m, TR), s,
+                               b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
+            return hipGetLastError();
+        }
+    }
     if (m.wl == 4 && m.nleft == 0)      // no narrow last block, no left-over columns: the variant without that code
         hipLaunchKernelGGL((k_step<POT, GEN, RPW, false>), grid_blocks(m), dim3(64 * kTileRows / RPW), step_lds_bytes(m), s,
                            b.P[par], b.X[par], b.tgt, b.V[par], b.Vinit, b.S[par], b.X[q], b.V[q], b.P[q], b.S[q], m, p, fp);
@@ -199,32 +216,32 @@ static hipError_t launch_step_r(const DevModel& m0, const DevStep& p, const DevF
     return hipGetLastError();
 }
 template <int POT, bool GEN>
-static hipError_t launch_step_t(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par,
+static hipError_t launch_step_t(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par, bool wide,
                                 hipStream_t s) {
     switch (m.rpw) {
-        case 1: return launch_step_r<POT, GEN, 1>(m, p, fp, b, par, s);
-        case 2: return launch_step_r<POT, GEN, 2>(m, p, fp, b, par, s);
-        default: return launch_step_r<POT, GEN, 4>(m, p, fp, b, par, s);
+        case 1: return launch_step_r<POT, GEN, 1>(m, p, fp, b, par, wide, s);
+        case 2: return launch_step_r<POT, GEN, 2>(m, p, fp, b, par, wide, s);
+        default: return launch_step_r<POT, GEN, 4>(m, p, fp, b, par, wide, s);
     }
 }
 
 hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int parity,
-                       bool general_tail, hipStream_t s) {
+                       bool general_tail, bool wide, hipStream_t s) {
     if (!general_tail) {
         switch (m.noe_pot) {
-            case 0: return launch_step_t<0, false>(m, p, fp, b, parity, s);
-            case 1: return launch_step_t<1, false>(m, p, fp, b, parity, s);
-            case 3: return launch_step_t<3, false>(m, p, fp, b, parity, s);
-            case 4: return launch_step_t<4, false>(m, p, fp, b, parity, s);
-            default: return launch_step_t<2, false>(m, p, fp, b, parity, s);
+            case 0: return launch_step_t<0, false>(m, p, fp, b, parity, wide, s);
+            case 1: return launch_step_t<1, false>(m, p, fp, b, parity, wide, s);
+            case 3: return launch_step_t<3, false>(m, p, fp, b, parity, wide, s);
+            case 4: return launch_step_t<4, false>(m, p, fp, b, parity, wide, s);
+            default: return launch_step_t<2, false>(m, p, fp, b, parity, wide, s);
         }
     }
     switch (m.noe_pot) {
-        case 0: return launch_step_t<0, true>(m, p, fp, b, parity, s);
-        case 1: return launch_step_t<1, true>(m, p, fp, b, parity, s);
-        case 3: return launch_step_t<3, true>(m, p, fp, b, parity, s);
-        case 4: return launch_step_t<4, true>(m, p, fp, b, parity, s);
-        default: return launch_step_t<2, true>(m, p, fp, b, parity, s);
+        case 0: return launch_step_t<0, true>(m, p, fp, b, parity, wide, s);
+        case 1: return launch_step_t<1, true>(m, p, fp, b, parity, wide, s);
+        case 3: return launch_step_t<3, true>(m, p, fp, b, parity, wide, s);
+        case 4: return launch_step_t<4, true>(m, p, fp, b, parity, wide, s);
+        default: return launch_step_t<2, true>(m, p, fp, b, parity, wide, s);
     }
 }
 

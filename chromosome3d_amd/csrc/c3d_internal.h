@@ -89,8 +89,9 @@ struct DevBuffers {
 };
 
 // host-callable launchers (defined in c3d_device.hip)
+// wide: 16 rows a workgroup and four a wave (the shipped potential, clamp forms, no narrow last block; the caller decides: n > 1024)
 hipError_t launch_step(const DevModel& m, const DevStep& p, const DevFire& fp, const DevBuffers& b, int parity,
-                       bool general_tail, hipStream_t s);
+                       bool general_tail, bool wide, hipStream_t s);
 hipError_t launch_eval_forces(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float* Fout,
                               bool general_tail, int rows_per_wave, hipStream_t s);
 hipError_t launch_energy(const DevModel& m, const DevStep& p, const DevBuffers& b, int parity, float s_noe,

@@ -416,20 +416,27 @@ __device__ __forceinline__ void pair_term2(const PairK2& k, float2v v2, float2v 
 // as two float4: (a.x, b.x, a.y, b.y), (a.z, b.z, a.w, b.w)
 template <int POT, bool GEN, int RPW, bool NC>
 __device__ __forceinline__ bool pair_targets_in_use(const DevModel& m) {
-    if constexpr (POT == 4 && !GEN && RPW == 2 && !NC) return m.tgs2 != nullptr; else return false;
+    if constexpr (POT == 4 && !GEN && (RPW == 2 || RPW == 4) && !NC) return m.tgs2 != nullptr; else return false;
 }
+// tv[2q], tv[2q + 1] = the two float4 of row pair q of the wave (a wave whose rows lie beyond the last bead re-reads the last pair: in bounds)
 template <int RPW>
 __device__ __forceinline__ void pair_targets_prefetch(const DevModel& m, int row0, int lane, int jb, float4 (&tv)[RPW]) {
-    if constexpr (RPW == 2) {
-        const float4* src = reinterpret_cast<const float4*>(m.tgs2 + (((size_t)(row0 >> 1) * (m.npad >> 8) + jb) * 64 + lane) * 8);
-        tv[0] = src[0]; tv[1] = src[1];
+    if constexpr (RPW == 2 || RPW == 4) {
+        const int last = ((m.n + 1) >> 1) - 1;
+#pragma unroll
+        for (int q = 0; q < RPW / 2; ++q) {
+            const int pr = min((row0 >> 1) + q, last);
+            const float4* src = reinterpret_cast<const float4*>(m.tgs2 + (((size_t)pr * (m.npad >> 8) + jb) * 64 + lane) * 8);
+            tv[2 * q] = src[0]; tv[2 * q + 1] = src[1];
+        }
     }
 }
 // targets streamed from global memory, one column block ahead (per-step kernel)
 // NC = false: the instantiation for problems whose last block is a full one and that leave no column over (m.wl == 4,
 // m.nleft == 0: every N > 1024 among them) carries none of the narrow-column code — the per-step kernel is launched once per SA
 // step and pays for every kilobyte of code it drags along (N = 2500: 26.5 against 27.2 us per step)
-template <int POT, bool GEN, int RPW, bool NC = true, bool PACKED = true>
+// PACKED4 = the packed form also at four rows per wave (two row pairs: the wide-tile step kernel of large problems, NC = false)
+template <int POT, bool GEN, int RPW, bool NC = true, bool PACKED = true, bool PACKED4 = false>
 __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p, const float* __restrict__ tgt,
                                             const float* xs, const float* ys, const float* zs, int row0, int lane,
                                             float4 (&tv)[RPW], float& Fx, float& Fy, float& Fz) {
@@ -506,6 +513,46 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
         }
 #undef C3D_PK_COL
         fx[0] = fx2.x; fx[1] = fx2.y; fy[0] = fy2.x; fy[1] = fy2.y; fz[0] = fz2.x; fz[1] = fz2.y;
+        reduce_and_chain<POT, RPW, GEN, NC>(m, p, tgt, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
+        return;
+    }
+    if constexpr (POT == 4 && !GEN && RPW == 4 && !NC && PACKED4 && PACKED && C3D_PACKED_STEP) {
+        // the same with four rows per wave: two row pairs sharing the column loads and the loop (the wide-tile step kernel; written out
+        // apart from the two-row form above so that form's code stays what it was).  Resident pair targets only (DevModel::tgs2: the
+        // launcher falls back to the two-row form without them), streamed ONE column block ahead: the register budget of four rows.
+        constexpr int Q = RPW / 2;
+        const PairK2 k2 = pair_k2(m, p);
+        float2v xi2[Q], yi2[Q], zi2[Q], fx2[Q], fy2[Q], fz2[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            xi2[q] = float2v{xi[2 * q], xi[2 * q + 1]}; yi2[q] = float2v{yi[2 * q], yi[2 * q + 1]}; zi2[q] = float2v{zi[2 * q], zi[2 * q + 1]};
+            fx2[q] = float2v{0.0f, 0.0f}; fy2[q] = fx2[q]; fz2[q] = fx2[q];
+        }
+        const float2v on2 = float2v{m.inv_rs, m.inv_rs};
+        for (int jb = 0; jb < nfull; ++jb) {
+            float4 t1[RPW];
+            pair_targets_prefetch<RPW>(m, row0, lane, min(jb + 1, nblk - 1), t1);      // the last block re-reads itself (in bounds)
+            const int j = 256 * jb + 4 * lane;
+            const float4 xj = *reinterpret_cast<const float4*>(xs + j);
+            const float4 yj = *reinterpret_cast<const float4*>(ys + j);
+            const float4 zj = *reinterpret_cast<const float4*>(zs + j);
+            const float2v x01 = float2v{xj.x, xj.y}, x23 = float2v{xj.z, xj.w}, y01 = float2v{yj.x, yj.y}, y23 = float2v{yj.z, yj.w};
+            const float2v z01 = float2v{zj.x, zj.y}, z23 = float2v{zj.z, zj.w};
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                pair_term2<0>(k2, float2v{tv[2 * q].x, tv[2 * q].y}, on2, xi2[q], yi2[q], zi2[q], x01, y01, z01, fx2[q], fy2[q], fz2[q]);
+                pair_term2<1>(k2, float2v{tv[2 * q].z, tv[2 * q].w}, on2, xi2[q], yi2[q], zi2[q], x01, y01, z01, fx2[q], fy2[q], fz2[q]);
+                pair_term2<0>(k2, float2v{tv[2 * q + 1].x, tv[2 * q + 1].y}, on2, xi2[q], yi2[q], zi2[q], x23, y23, z23, fx2[q], fy2[q], fz2[q]);
+                pair_term2<1>(k2, float2v{tv[2 * q + 1].z, tv[2 * q + 1].w}, on2, xi2[q], yi2[q], zi2[q], x23, y23, z23, fx2[q], fy2[q], fz2[q]);
+                asm volatile("" : "+v"(fx2[q]), "+v"(fy2[q]), "+v"(fz2[q]));      // one row pair's terms in flight at a time (register budget)
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) tv[r] = t1[r];
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            fx[2 * q] = fx2[q].x; fx[2 * q + 1] = fx2[q].y; fy[2 * q] = fy2[q].x; fy[2 * q + 1] = fy2[q].y; fz[2 * q] = fz2[q].x; fz[2 * q + 1] = fz2[q].y;
+        }
         reduce_and_chain<POT, RPW, GEN, NC>(m, p, tgt, xs, ys, zs, row0, lane, fx, fy, fz, Fx, Fy, Fz);
         return;
     }

@@ -134,23 +134,35 @@ def test_symmetric_tile_step_matches_oracle_and_per_step_kernel(solver, n):
         assert np.abs(out[1][1][r] - vo).max() < 2e-3 * max(1.0, np.abs(vo).max())
 
 
-def test_resident_pair_targets_change_no_bit(solver):
+@pytest.mark.parametrize("n", [1101, 1041])
+def test_resident_pair_targets_change_no_bit_and_wide_tiles_agree(solver, n):
     """Beyond the cluster kernel's reach (n > 1024) the per-step kernel of the shipped potential reads pre-scaled targets of row pairs
     (DevModel::tgs2: t / mrs, "no restraint" as 1e30) instead of forming the pair constants from the target matrix in every step: same
     operations per restrained pair, an exact zero either way for the others — the trajectories must agree bit for bit (option
-    pair_targets 0 = the constants formed per step).  An odd bead count: the last row pair's second row is a repeat of the last bead."""
+    pair_targets 0 = the constants formed per step; option wide_tiles 0 = the narrow form of the kernel, eight rows a workgroup and one
+    packed row pair a wave).  The wide form — 16 rows a workgroup, two packed row pairs a wave, resident targets only: the default —
+    against the narrow one: another order of a row's sum, so within rounding after 50 chaotic steps, not bitwise.  Odd bead counts: the last row pair's second row is a repeat of the last bead; n = 1041: an odd number of 8-row
+    tiles, the last workgroup of the wide form owns one."""
     from chromosome3d_amd import default_fire, default_model, make_stages, pipeline
-    IF, _ = synthetic_if(1101, seed=11)
+    IF, _ = synthetic_if(n, seed=11)
     stages = make_stages([(2, 12, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 25, 0.003, 0.4, 0.003, 0.9, 2000.0), (1, 13, 0.005, 1.0, 0.5, 0.9, 1000.0)])
-    out = []
-    for on in (1, 0):
-        solver.set_option("pair_targets", on)
-        solver.set_model(default_model())
-        pipeline.IF2dist_new(solver, IF)
-        solver.set_schedule(stages, default_fire(), 0.0, 250)
-        solver.init_replicas(3, 82364, 0)
-        assert solver.run_steps(10 ** 6) == 50
-        assert "k_step<4, false, 2, false>" in solver.step_kernel_name
-        out.append(solver.coords().copy())
-    solver.set_option("pair_targets", 1)
-    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
+    out = {}
+    try:
+        for wide, on in ((1, 1), (0, 1), (0, 0), (1, 0)):
+            solver.set_option("wide_tiles", wide)
+            solver.set_option("pair_targets", on)
+            solver.set_model(default_model())
+            pipeline.IF2dist_new(solver, IF)
+            solver.set_schedule(stages, default_fire(), 0.0, 250)
+            solver.init_replicas(3, 82364, 0)
+            assert solver.run_steps(10 ** 6) == 50
+            # (the wide form reads the resident pair targets only: without them the launcher takes the narrow form)
+            assert ("k_step<4, false, 4, false, 16, true>" if wide and on else "k_step<4, false, 2, false, 8, false>") in solver.step_kernel_name
+            out[wide, on] = (solver.coords().copy(), solver.velocities().copy())
+    finally:
+        solver.set_option("pair_targets", 1)
+        solver.set_option("wide_tiles", 1)
+    assert np.isfinite(out[1, 1][0]).all() and np.isfinite(out[0, 1][0]).all()
+    for a, b in (((0, 1), (0, 0)), ((0, 0), (1, 0))):
+        assert np.array_equal(out[a][0], out[b][0]) and np.array_equal(out[a][1], out[b][1])
+    assert np.abs(out[1, 1][0] - out[0, 1][0]).max() < 2e-3 and np.abs(out[1, 1][1] - out[0, 1][1]).max() < 2e-2
