@@ -137,6 +137,10 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *   pair_targets    1 (default) / 0: beyond the multi-step kernel's reach (n > 1024) the per-step kernel of the shipped potential reads
  *                   resident pre-scaled targets of row pairs (built once per matrix and model) instead of forming the per-pair
  *                   constants from the target matrix in every step.  Same bits either way (measurement knob)
+ *   wide_tiles      1 (default) / 0: beyond the multi-step kernel's reach (n > 1024) the per-step kernel of the shipped potential runs 16 rows
+ *                   a workgroup and four a wave (two packed row pairs; needs pair_targets 1) instead of 8 and two: a wave's fixed work per
+ *                   step is shared by twice the pair terms (N = 2500 x 8: 29.8 -> 26.2 us per step).  Another order of a row's sum: equal
+ *                   within rounding, not bitwise (measurement knob)
  *   start           0 (default) random coil, 1 extended strand (chromosome3D.pl:2413-2416)
  *   use_graph       != 0: per-step path replays hipGraphs (default 1)
  *   replica_groups  1..4 stream groups of the per-step path (default 2);  graph_chunk, rows_per_wave,
