@@ -122,19 +122,20 @@ def test_symmetric_tile_step_matches_oracle_and_per_step_kernel(solver, n):
         assert solver.run_steps(10 ** 6) == 40
         out[sym] = (solver.coords(), solver.velocities(), solver.step_kernel_name)
     solver.set_option("symmetric", 0)
-    assert "k_pairs_sym" in out[1][2] and "k_step" in out[0][2]
+    assert "k_pairs_sym" in out[1][2] and "k_step<4, false, 4, false, 16, true>" in out[0][2]
     assert np.abs(out[1][0] - out[0][0]).max() < 5e-4 and np.abs(out[1][1] - out[0][1]).max() < 5e-3
     om, of = oracle_model_from(m, n), oracle_fire_from(fire)
     for r in range(2):
         xo, vo, ev = O.run_schedule(om, d10, O.make_stages(stages), of, 82364, r, x0=x0[r].astype(np.float64))
-        xc = out[1][0][r].astype(np.float64)
-        xc -= xc.mean(0)
         assert ev == 40
-        assert np.abs(xc - xo).max() < 2e-3, np.abs(xc - xo).max()
-        assert np.abs(out[1][1][r] - vo).max() < 2e-3 * max(1.0, np.abs(vo).max())
+        for form in (1, 0):      # symmetric tiles; the per-step kernel (its wide form beyond n = 1024: 16 rows a workgroup, four a wave)
+            xc = out[form][0][r].astype(np.float64)
+            xc -= xc.mean(0)
+            assert np.abs(xc - xo).max() < 2e-3, (form, np.abs(xc - xo).max())
+            assert np.abs(out[form][1][r] - vo).max() < 2e-3 * max(1.0, np.abs(vo).max())
 
 
-@pytest.mark.parametrize("n", [1101, 1041])
+@pytest.mark.parametrize("n", [1101, 1041, 1025, 2049])
 def test_resident_pair_targets_change_no_bit_and_wide_tiles_agree(solver, n):
     """Beyond the cluster kernel's reach (n > 1024) the per-step kernel of the shipped potential reads pre-scaled targets of row pairs
     (DevModel::tgs2: t / mrs, "no restraint" as 1e30) instead of forming the pair constants from the target matrix in every step: same
@@ -142,7 +143,7 @@ def test_resident_pair_targets_change_no_bit_and_wide_tiles_agree(solver, n):
     pair_targets 0 = the constants formed per step; option wide_tiles 0 = the narrow form of the kernel, eight rows a workgroup and one
     packed row pair a wave).  The wide form — 16 rows a workgroup, two packed row pairs a wave, resident targets only: the default —
     against the narrow one: another order of a row's sum, so within rounding after 50 chaotic steps, not bitwise.  Odd bead counts: the last row pair's second row is a repeat of the last bead; n = 1041: an odd number of 8-row
-    tiles, the last workgroup of the wide form owns one."""
+    tiles, the last workgroup of the wide form owns one; n = 1025 and 2049: that tile holds a single bead."""
     from chromosome3d_amd import default_fire, default_model, make_stages, pipeline
     IF, _ = synthetic_if(n, seed=11)
     stages = make_stages([(2, 12, 0.0, 1.0, 20.0, 0.5, 0.0), (0, 25, 0.003, 0.4, 0.003, 0.9, 2000.0), (1, 13, 0.005, 1.0, 0.5, 0.9, 1000.0)])
