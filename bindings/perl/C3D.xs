@@ -106,7 +106,7 @@ solve(matrix_path, out_dir, id, models, K, alpha, seed, device, embed)
         rho = (double*)malloc(sizeof(double) * models);
         C3D_TRY(c3d_get_coords(ctx, xyz));
         C3D_TRY(c3d_get_energies(ctx, en));
-        C3D_TRY(c3d_spearman_if_dist_batch(IF, xyz, n, models, 3, rho));
+        C3D_TRY(c3d_score_replicas(ctx, IF, 3, NULL, NULL, rho));      /* on the device, from the resident coordinates (K6): 3 ms instead of ~35 on the host at N = 455 */
         for (k = 0; k < models; ++k) {
             snprintf(name, sizeof name, "%s_%d.pdb", id, k + 1);
             snprintf(path, sizeof path, "%s/%s", out_dir, name);

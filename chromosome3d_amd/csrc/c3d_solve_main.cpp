@@ -161,7 +161,7 @@ int main(int argc, char** argv) {
                n, R, models, steps, ms, device, ms > 0 ? 1e3 * (double)steps * models / ms : 0.0);
         if (IF) {
             std::vector<double> rho(models);
-            if (c3d_spearman_if_dist_batch(IF, xyz.data(), n, models, 3, rho.data()) == C3D_OK)
+            if (c3d_score_replicas(ctx, IF, 3, nullptr, nullptr, rho.data()) == C3D_OK)      // on the device, from the resident coordinates (K6)
                 for (int r = 0; r < models; ++r)
                     printf("  model %2u  E_noe %14.2f  Spearman(IF,d) %.4f\n", first_rep + r + 1, en[3 * r], rho[r]);
         }
