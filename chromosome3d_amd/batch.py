@@ -77,7 +77,7 @@ def solve_assigned(solver, mats, mine, models=20, seed=82364, min_steps=3000, gt
         if on_job:
             on_job(cid, solver)
         x, e = solver.coords(), solver.energies()
-        rho = pipeline.spearman_IF_models(IF, x)
+        rho = solver.score(IF)[2]           # K6 on the device, from the resident coordinates (= pipeline.spearman_IF_models(IF, x) to rounding)
         r = np.zeros((models, 5))
         r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4] = k, np.arange(models), e[:, 0], rho, solver.last_timing()[0]
         recs.append(r)
