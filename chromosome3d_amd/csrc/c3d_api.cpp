@@ -168,6 +168,8 @@ struct c3d_ctx {
     std::vector<c3d::StepRun> prog_runs;
     unsigned* h_tmo = nullptr;             // hipHostMalloc'ed, mapped
     void* h_stage = nullptr;               // pinned host staging of the read-backs (ensure_stage)
+    void* d_score = nullptr;               // c3d_score_replicas' device scratch (ranks, rounded coordinates, sums, histograms), grown on demand
+    size_t d_score_bytes = 0;
     size_t h_stage_bytes = 0;
     std::thread preload;                   // loads the code objects of the job's kernels while the caller is busy on the host (c3d_create)
     unsigned* h_tmo_dev = nullptr;         // its device address
@@ -855,6 +857,7 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
     dev_free(c->d_prog); dev_free(c->d_claim);
     if (c->h_tmo) (void)hipHostFree(c->h_tmo);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    dev_free(c->d_score);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->kev0) hipEventDestroy(c->kev0);
@@ -1459,20 +1462,28 @@ extern "C" int c3d_score_replicas(c3d_ctx* c, const double* IF, int range, int32
     std::vector<double> rankA;
     size_t m = 0;
     double ma = 0, saa = 0;
-    DevTmp<double> d_rank, d_xr, d_part;
-    DevTmp<unsigned> d_hist, d_below;
-    DevTmp<int> d_ovf;
+    // one scratch allocation the context keeps (a hipMalloc / hipFree pair of the two 21 MB histograms alone cost about a millisecond per call)
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_rank = up(sizeof(double) * (size_t)n * n), b_xr = up(sizeof(double) * 3 * (size_t)n * nrep), b_part = up(sizeof(double) * 4 * (size_t)n * nrep),
+                 b_hist = up(sizeof(unsigned) * (size_t)nbins * nrep);
+    const size_t need = b_rank + b_xr + b_part + 2 * b_hist + 256;
+    if (need > c->d_score_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dev_free(c->d_score);
+        c->d_score_bytes = 0;
+        HIP_TRY(hipMalloc(&c->d_score, need));
+        c->d_score_bytes = need;
+    }
+    char* const base = static_cast<char*>(c->d_score);
+    struct { double* p; } d_rank{reinterpret_cast<double*>(base)}, d_xr{reinterpret_cast<double*>(base + b_rank)}, d_part{reinterpret_cast<double*>(base + b_rank + b_xr)};
+    struct { unsigned* p; } d_hist{reinterpret_cast<unsigned*>(base + b_rank + b_xr + b_part)}, d_below{reinterpret_cast<unsigned*>(base + b_rank + b_xr + b_part + b_hist)};
+    struct { int* p; } d_ovf{reinterpret_cast<int*>(base + b_rank + b_xr + b_part + 2 * b_hist)};
     if (IF && rho) {
         c3d::if_pair_ranks(IF, n, range, rankA, m, ma, saa);
         if (m < 2) return fail(C3D_ERR_INVALID, "c3d_score_replicas: range leaves no pairs");
-        HIP_TRY(hipMalloc(&d_rank.p, sizeof(double) * rankA.size()));
         HIP_TRY(hipMemcpyAsync(d_rank.p, rankA.data(), sizeof(double) * rankA.size(), hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(hipMalloc(&d_xr.p, sizeof(double) * 3 * (size_t)n * nrep));
-    HIP_TRY(hipMalloc(&d_part.p, sizeof(double) * 4 * (size_t)n * nrep));
-    HIP_TRY(hipMalloc(&d_hist.p, sizeof(unsigned) * (size_t)nbins * nrep));
-    HIP_TRY(hipMalloc(&d_below.p, sizeof(unsigned) * (size_t)nbins * nrep));
-    HIP_TRY(hipMalloc(&d_ovf.p, sizeof(int)));
+    else d_rank.p = nullptr;
     const double mb = 0.5 * ((double)m + 1.0);     // mean of the ranks 1..m, ties or not
     hipError_t e = c3d::launch_score(c->buf.X[c->parity], c->buf.tgt, d_rank.p, n, c->npad, nrep, range, c->model.min_sep, nbins, ma,
                                      mb, 0.5, d_xr.p, d_hist.p, d_below.p, d_part.p, d_ovf.p, c->stream);
