@@ -238,6 +238,7 @@ extern "C" int c3d_read_tbl(const char* path, int32_t** ri, int32_t** rj, int32_
             if (q > b0) { if (nt < 14) tok[nt] = base + b0; ++nt; }
         }
         const std::string line = nt == 0 || (nt >= 14 && strncmp(tok[0], "assign", 6) == 0) ? std::string() : txt.substr(p, e - p);
+        const size_t p0 = p;
         p = e + 1;
         if (nt == 0) continue;
         if (strncmp(tok[0], "assign", 6) != 0) return fail(C3D_ERR_IO, std::string("contact.tbl: unexpected row: ") + line);
@@ -247,6 +248,8 @@ extern "C" int c3d_read_tbl(const char* path, int32_t** ri, int32_t** rj, int32_
         double tv;
         const std::from_chars_result fc = std::from_chars(tok[11], base + e, tv);
         if (fc.ec != std::errc() || (fc.ptr < base + e && !is_ws(*fc.ptr))) tv = strtod(tok[11], nullptr);
+        if (!(std::fabs(tv) < 1e7) || vi.back() < 1 || vj.back() < 1)       // NaN fails the comparison; atoi of a non-number gives 0
+            return fail(C3D_ERR_IO, std::string("contact.tbl: bad residue number or distance: ") + txt.substr(p0, e - p0));
         vt.push_back((int32_t)llround(tv * 10.0));
     }
     const size_t r = vi.size();
@@ -285,9 +288,33 @@ extern "C" int c3d_set_residue_sequence(const char* seq1) {
     return C3D_OK;
 }
 
+// Coordinates every host helper below accepts: finite and inside what a PDB's %8.3f columns hold (chromosome3D.pl:678-687 reads x, y, z
+// from columns 31-54; a value that does not fit its eight columns shifts every later field).  Anything else is C3D_ERR_INVALID with a
+// message — never rows of garbage, never an out-of-range float -> integer conversion (the device path reports a trajectory that blew up
+// as C3D_ERR_DIVERGED; these helpers take coordinates from any caller).
+static int check_coords(const float* xyz, size_t count, const char* who) {
+    for (size_t k = 0; k < count; ++k) {
+        const double v = (double)xyz[k];
+        if (!(v > -999.9995 && v < 9999.9995)) {       // NaN fails both comparisons
+            char msg[160];
+            snprintf(msg, sizeof msg, "%s: coordinate %zu of bead %zu is %s (a PDB holds -999.999 .. 9999.999)", who, k % 3, k / 3 + 1,
+                     std::isfinite(v) ? "out of range" : "not finite");
+            return fail(C3D_ERR_INVALID, msg);
+        }
+    }
+    return C3D_OK;
+}
+static int check_coords_d(const double* xyz, size_t count, const char* who) {
+    for (size_t k = 0; k < count; ++k)
+        if (!(std::fabs(xyz[k]) < 1e6)) return fail(C3D_ERR_INVALID, std::string(who) + ": coordinates not finite or out of range");
+    return C3D_OK;
+}
+
 extern "C" int c3d_write_pdb(const char* path, const float* xyz, int n, double e_noe, double e_bond, double e_rep,
                              const char* title) {
     if (!path || !xyz || n < 1) return fail(C3D_ERR_INVALID, "c3d_write_pdb: bad arguments");
+    if (!std::isfinite(e_noe) || !std::isfinite(e_bond) || !std::isfinite(e_rep)) return fail(C3D_ERR_INVALID, "c3d_write_pdb: energy not finite");
+    if (int rc = check_coords(xyz, (size_t)3 * n, "c3d_write_pdb")) return rc;
     FILE* f = fopen(path, "w");
     if (!f) return fail(C3D_ERR_IO, std::string("cannot write ") + path);
     fprintf(f, "REMARK FILENAME=\"%s\"\n", title ? title : path);
@@ -462,7 +489,8 @@ static inline char* put_lit(char* o, const char* t, size_t len) { memcpy(o, t, l
 
 extern "C" int c3d_assess(const float* xyz, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10,
                           double relax, int* satisfied, double* sum_dev) {
-    if (!xyz || (R > 0 && (!ri || !rj || !rt10))) return fail(C3D_ERR_INVALID, "c3d_assess: null argument");
+    if (!xyz || n < 1 || R < 0 || (R > 0 && (!ri || !rj || !rt10)) || !std::isfinite(relax)) return fail(C3D_ERR_INVALID, "c3d_assess: bad arguments");
+    if (int rc = check_coords(xyz, (size_t)3 * n, "c3d_assess")) return rc;
     // the Perl reads coordinates back from the %8.3f PDB text
     std::vector<double> x((size_t)3 * n);
     for (size_t k = 0; k < x.size(); ++k) x[k] = round_dec3((double)xyz[k]);
@@ -491,7 +519,10 @@ extern "C" int c3d_assess(const float* xyz, int n, int R, const int32_t* ri, con
 // here: the order of the restraint rows).  20 models x 101 426 rows took the Perl driver 4 s, this loop 0.3 s with snprintf and 0.05 s without.
 extern "C" int c3d_write_violations(const float* xyz, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10, double relax,
                                     const char* pdb_label, const char* tbl_label, const char* path, int* satisfied, double* sum_dev) {
-    if (!xyz || !path || (R > 0 && (!ri || !rj || !rt10))) return fail(C3D_ERR_INVALID, "c3d_write_violations: null argument");
+    if (!xyz || !path || n < 1 || R < 0 || (R > 0 && (!ri || !rj || !rt10)) || !std::isfinite(relax)) return fail(C3D_ERR_INVALID, "c3d_write_violations: bad arguments");
+    if (int rc = check_coords(xyz, (size_t)3 * n, "c3d_write_violations")) return rc;
+    for (int k = 0; k < R; ++k)      // the row buffer below is sized for targets a "%.1f" distance file can hold
+        if (rt10[k] < -100000000 || rt10[k] > 100000000) return fail(C3D_ERR_INVALID, "c3d_write_violations: target out of range");
     std::vector<double> x((size_t)3 * n);
     for (size_t k = 0; k < x.size(); ++k) x[k] = round_dec3((double)xyz[k]);
     int count = 0;
@@ -620,6 +651,8 @@ extern "C" int c3d_spearman_if_dist_batch(const double* IF, const float* xyz, in
     std::vector<double> rank_matrix, ra;
     size_t m = 0;
     double ma = 0, saa = 0;
+    for (size_t k = 0; k < (size_t)n * n; ++k)
+        if (std::isnan(IF[k])) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist_batch: the matrix holds a NaN");
     c3d::if_pair_ranks(IF, n, range, rank_matrix, m, ma, saa);
     if (m < 2) return fail(C3D_ERR_INVALID, "c3d_spearman_if_dist_batch: range leaves no pairs");
     std::vector<uint32_t> pi, pj;
@@ -632,6 +665,7 @@ extern "C" int c3d_spearman_if_dist_batch(const double* IF, const float* xyz, in
         }
     std::vector<double> x((size_t)3 * n), rb(m);
     std::vector<long long> dq(m);
+    if (int rc = check_coords(xyz, (size_t)3 * n * n_models, "c3d_spearman_if_dist_batch")) return rc;
     for (int mdl = 0; mdl < n_models; ++mdl) {
         const float* xm = xyz + (size_t)mdl * n * 3;
         for (size_t k = 0; k < x.size(); ++k) x[k] = round_dec3((double)xm[k]);
@@ -673,6 +707,7 @@ extern "C" int c3d_spearman_if_dist(const double* IF, const float* xyz, int n, i
 // number of similarity.txt to 1e-12.
 extern "C" int c3d_reduce_model(const double* xyz, int n, double* out) {
     if (!xyz || !out || n < 1) return fail(C3D_ERR_INVALID, "c3d_reduce_model: bad arguments");
+    if (int rc = check_coords_d(xyz, (size_t)3 * n, "c3d_reduce_model")) return rc;
     const int m = (n + 1) / 2;
     for (int k = 0; k < m; ++k)
         for (int c = 0; c < 3; ++c) {
@@ -684,6 +719,8 @@ extern "C" int c3d_reduce_model(const double* xyz, int n, double* out) {
 
 extern "C" int c3d_model_similarity(const double* a, const double* b, int n, double* spearman, double* rmsd) {
     if (!a || !b || n < 3) return fail(C3D_ERR_INVALID, "c3d_model_similarity: bad arguments");
+    if (int rc = check_coords_d(a, (size_t)3 * n, "c3d_model_similarity")) return rc;
+    if (int rc = check_coords_d(b, (size_t)3 * n, "c3d_model_similarity")) return rc;
     const size_t m = (size_t)n * (n - 1) / 2;
     std::vector<double> da(m), db(m), ra, rb;
     size_t k = 0;

@@ -25,7 +25,7 @@ import re
 import numpy as np
 import pytest
 
-from tests.util import GOLD, bundled_rank, load_pdb_xyz, structure_report
+from tests.util import GOLD, bundled_rank, load_pdb_xyz, relax_reference_model, structure_report
 
 pytestmark = pytest.mark.gpu
 ALL = os.path.join(GOLD, "all45")
@@ -72,7 +72,12 @@ def _solve(solver, cid, nrep=20, seed=82364):
     solver.set_schedule(default_schedule(3000), default_fire(), 0.0, 250)
     solver.init_replicas(nrep, seed, 0)
     solver.run()
-    return structure_report(IF, solver.coords(), solver.energies()[:, 0], Xr, bundled_rank(ref[0]), pipeline.restraints_from_dist10(d10))
+    x, e = solver.coords(), solver.energies()[:, 0]
+    rep = structure_report(IF, x, e, Xr, bundled_rank(ref[0]), pipeline.restraints_from_dist10(d10))
+    rep["x_best"] = x[rep["best"]].astype(np.float64)
+    rep["file_rank"] = bundled_rank(ref[0])
+    rep["relaxed"] = relax_reference_model(solver, Xr, e)          # replaces the solver's replicas: last
+    return rep
 
 
 _CACHE = {}
@@ -94,13 +99,18 @@ def test_best_ranked_replica_within_the_north_star_tolerance(solver, cid):
     assert abs(r["delta"]) <= TOL, (cid, r["delta"])
 
 
-@pytest.mark.parametrize("cid", CIDS)
-def test_best_spearman_replica_within_the_north_star_tolerance(solver, cid):
-    """Like for like with how the bundled file was chosen (not the reference's energy-best: ranks 1..10 in the file names): the best
-    Spearman among our 20 replicas within +-0.01 of the bundled model's — ALL 45, no allow-list (seed 82364; 44-45 of 45 for each of 8
-    seeds, profiles/r04_seed_robustness_all45.md) — and some replica of ours within +-0.01 of the reference's value."""
-    r = _report(solver, cid)
-    assert abs(r["delta_max"]) <= TOL and abs(r["delta_closest"]) <= TOL, (cid, r["delta_max"], r["delta_closest"])
+def test_information_only_best_spearman_replica(solver):
+    """INFORMATION, not the acceptance gate (the gate is the best-ENERGY reading above, two named strict xfails, hard bounds in
+    test_all_45_bundled_matrices_spearman): picking our replica by the metric under test is biased towards passing.  It is reported
+    because the bundled file was itself picked from the reference's run (ranks 1..10 in the names, never 11..20): the best Spearman among
+    ALL 20 of ours, and — the reading the file names support — among our TEN lowest-energy replicas, against the bundled model's."""
+    reps = {cid: _report(solver, cid) for cid in CIDS}
+    dx = np.array([r["delta_max"] for r in reps.values()])
+    dt = np.array([r["delta_max_top10"] for r in reps.values()])
+    dc = np.array([r["delta_closest"] for r in reps.values()])
+    print("best Spearman of 20: within 0.01 %d, bias %+.4f; of the 10 lowest-energy: within 0.01 %d, bias %+.4f; closest: %d" %
+          ((np.abs(dx) <= TOL).sum(), dx.mean(), (np.abs(dt) <= TOL).sum(), dt.mean(), (np.abs(dc) <= TOL).sum()))
+    assert (np.abs(dx) <= TOL).sum() >= 44 and (np.abs(dt) <= TOL).sum() >= 42 and (np.abs(dc) <= TOL).sum() >= 44
 
 
 def test_headline_config_margin(solver):
@@ -181,6 +191,72 @@ def test_all_45_the_references_own_assessment_of_our_models(solver):
     ours = reps["chr1_500kb"]["assess"]
     assert ours["R"] == 101426 and ours["ref"][0] == 10778 and abs(ours["ref"][1] - 374370.87) < 0.5       # the reference's own line for its model
     assert abs(ours["best"][1] / ours["ref"][1] - 1.0) <= 0.02 and abs(ours["best"][0] / ours["ref"][0] - 1.0) <= 0.05
+
+
+def test_reference_energy_ranks_against_ours(solver):
+    """The one reference-held datum on ENERGY ORDERING: every bundled file name carries the model's rank by CNS NOE energy in the
+    reference's own run of 20 (chr22_1mb_rank08, chr4_1mb_rank10, ...; rule chromosome3D.pl:796-802, 822-828), all of them 1..10.  Each
+    bundled model is relaxed under OUR energy (final minimisation stage only, from the bundled coordinates) and its int(E_noe) ranked among
+    the int(E_noe) of our 20 annealed replicas.  If our energy orders folds as CNS's does, the relaxed bundled model lands where the file
+    name says, within the scatter of two independent runs of 20.  Table: profiles/r05_parity_sweep_all45.md (last columns)."""
+    from scipy.stats import spearmanr
+    reps = {cid: _report(solver, cid) for cid in CIDS}
+    rk = np.array([r["relaxed"]["rank_in_ours"] for r in reps.values()])
+    fr = np.array([r["file_rank"] for r in reps.values()])
+    moved = np.array([r["relaxed"]["moved"][0] for r in reps.values()])
+    gap = np.array([r["relaxed"]["rel_gap"] for r in reps.values()])
+    print("relaxed bundled model: rank in ours", dict(zip(CIDS, rk.tolist())), "file", fr.tolist(), "rel gap to our best", np.round(gap, 4).tolist())
+    for c in EDGE:
+        print(c, "file rank", reps[c]["file_rank"], "-> rank in ours", reps[c]["relaxed"]["rank_in_ours"], "E_noe", int(reps[c]["relaxed"]["e_noe"]),
+              "moved", reps[c]["relaxed"]["moved"])
+    # the bundled model IS a minimum of our energy: relaxing it does not change the structure
+    assert moved.min() >= 0.985 and moved.mean() >= 0.997, (moved.min(), moved.mean())
+    assert ((rk >= 1) & (rk <= 21)).all()
+    # Measured (seed 82364, profiles/r05_parity_sweep_all45.md): the relaxed bundled model sits among our TEN lowest energies on 35 of 45
+    # rows (every file rank is <= 10), within 5 places of its file rank on 29, median place 4 (file: 4), above all 20 of ours on ONE row
+    # (chr16_1mb) — and BELOW all 20 of ours on 11 rows: there the reference's search found a deeper minimum of OUR energy than our 20
+    # anneals did (chr13_1mb by 3.4 %).  The rank correlation itself is weak (+0.10): our energy orders folds as CNS's does only coarsely.
+    # The two north-star outliers are exactly rows where it does not: chr22_1mb file rank 8 -> 19th of ours, chr7_1mb 2 -> 11th.
+    assert (rk <= 10).sum() >= 31 and (np.abs(rk - fr) <= 5).sum() >= 25 and (rk == 21).sum() <= 3 and 2 <= np.median(rk) <= 7, \
+        ((rk <= 10).sum(), (np.abs(rk - fr) <= 5).sum(), (rk == 21).sum(), np.median(rk), spearmanr(rk, fr)[0])
+    assert gap.min() >= -0.05 and gap.max() <= 0.06, (gap.min(), gap.max())   # never more than 5 % below our best / 6 % above it
+    for c in EDGE:                                                             # the named outliers: our energy ranks the bundled fold LOW
+        assert reps[c]["relaxed"]["rank_in_ours"] > reps[c]["file_rank"] + 5, (c, reps[c]["relaxed"]["rank_in_ours"])
+
+
+def test_order_statistics_of_how_the_bundled_model_was_picked(solver):
+    """`ref_percentile` = fraction of our 20 replicas whose Spearman lies below the bundled model's.  If the bundled model were the best
+    of 20 draws from OUR distribution it would exceed all 20 of ours on ~1/2 of the rows; the best of the TEN lowest-energy models (what the
+    file names say: ranks 1..10 only) on ~1/3; a random member on ~1/21 — and it would sit below all of ours on ~0 / ~0 / ~1/21 of them."""
+    reps = {cid: _report(solver, cid) for cid in CIDS}
+    pct = np.array([r["ref_percentile"] for r in reps.values()])
+    top, bottom = int((pct == 1).sum()), int((pct == 0).sum())
+    print("ref pct = 1 on", top, "rows, = 0 on", bottom, "of", len(pct))
+    # measured 13 / 2 of 45: what "best Spearman among the ten lowest-energy models" predicts (15 +- 3.2 / 0), 2.8 sd below "best of all
+    # 20" (22.5 +- 3.4), far above "a random member" (2.1).  The two rows at 0 are chr5_1mb and chr23_500kb (both within +-0.005).
+    assert 8 <= top <= 20 and bottom <= 4, (top, bottom)
+
+
+def test_cross_resolution_agreement_of_our_own_models(solver):
+    """SURVEY 8f-2, output_models/similarity.txt:1-75: the reference's 500 kb model, reduced to 1 Mb, against its 1 Mb model of the same
+    chromosome — Spearman of the pair distances 0.855-0.967, mean 0.925 over the 17 chromosomes it lists.  The same for OUR best-ranked
+    models of the shipped energy model (c3d_reduce_model + c3d_model_similarity, which reproduce that file to 1e-12 on the bundled
+    models: tests/test_abi_host.py).  Table: profiles/r05_cross_resolution.md."""
+    import json
+    from chromosome3d_amd import pipeline
+    ref = json.load(open(os.path.join(GOLD, "similarity_reference.json")))
+    chrs = sorted({re.match(r"(chr\d+)_", k).group(1) for k in ref}, key=lambda c: int(c[3:]))
+    assert len(chrs) == 17
+    ours, theirs = [], []
+    for c in chrs:
+        a, b = _report(solver, f"{c}_500kb"), _report(solver, f"{c}_1mb")
+        rho, _ = pipeline.model_similarity(pipeline.reduce_model(a["x_best"]), b["x_best"])
+        ours.append(rho)
+        theirs.append([v["spearman"] for k, v in ref.items() if k.startswith(c + "_")][0])
+    ours, theirs = np.array(ours), np.array(theirs)
+    print("cross-resolution Spearman ours", np.round(ours, 4).tolist(), "mean", ours.mean(), "min", ours.min(), "reference mean", theirs.mean(), "min", theirs.min())
+    assert abs(theirs.mean() - 0.925) < 1e-3 and abs(theirs.min() - 0.855) < 1e-3
+    assert ours.mean() >= 0.92 and ours.min() >= 0.85, (ours.mean(), ours.min())
 
 
 def test_k1_bit_exact_on_all_45(solver):

@@ -388,11 +388,14 @@ def test_fp64_path_follows_the_oracle_over_long_trajectories(solver, O, cid, nst
         solver.set_option("precision", 32)
 
 
-def test_fp32_product_against_the_fp64_reference_statistics(solver):
-    """What fp32 costs: the full default schedule, 20 replicas of chr21_1mb, in both precisions.  Trajectories differ
-    (chaos), the ensembles do not: Spearman(IF, 1/d) mean and best within 0.003, median NOE energy within 1 %."""
+@pytest.mark.parametrize("cid", ["chr21_1mb", "chr1_500kb"])
+def test_fp32_product_against_the_fp64_reference_statistics(solver, cid):
+    """What fp32 costs (the bench line's `dtype` is narrower than the reference's arithmetic): the full default schedule, 20 replicas, in
+    both precisions — at N = 37 and at the HEADLINE workload, chr1_500kb x 20 (N = 455; the fp64 anneal takes ~55 ms there).
+    Trajectories differ (chaos), the ensembles do not: Spearman(IF, 1/d) mean and best within 0.003, median NOE energy within 1 %, and
+    the two ensembles overlap replica by replica (the fp32 mean inside the fp64 range and the other way round)."""
     from chromosome3d_amd import default_fire, default_model, default_schedule, pipeline
-    IF = load_if("chr21_1mb")
+    IF = load_if(cid)
     res = {}
     for prec in (64, 32):
         solver.set_option("precision", prec)
@@ -401,11 +404,13 @@ def test_fp32_product_against_the_fp64_reference_statistics(solver):
         solver.set_schedule(default_schedule(3000), default_fire(), 0.0, 250)
         solver.init_replicas(20, 82364, 0)
         solver.run()
+        assert solver.step_kernel_name.startswith("c3d::k64_step<") == (prec == 64), solver.step_kernel_name
         rho = -pipeline.spearman_IF_models(IF, solver.coords())
-        res[prec] = (rho.mean(), rho.max(), float(np.median(solver.energies()[:, 0])))
+        res[prec] = (rho.mean(), rho.max(), float(np.median(solver.energies()[:, 0])), rho.min())
     solver.set_option("precision", 32)
-    assert abs(res[64][0] - res[32][0]) < 0.003 and abs(res[64][1] - res[32][1]) < 0.003
-    assert abs(res[64][2] - res[32][2]) < 0.01 * res[64][2]
+    assert abs(res[64][0] - res[32][0]) < 0.003 and abs(res[64][1] - res[32][1]) < 0.003, res
+    assert abs(res[64][2] - res[32][2]) < 0.01 * res[64][2], res
+    assert res[64][3] <= res[32][0] <= res[64][1] and res[32][3] <= res[64][0] <= res[32][1], res
 
 
 def test_graph_replay_is_bitwise_eager(solver):
