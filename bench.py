@@ -11,8 +11,10 @@ equal N.  `--dist` initialises the RCCL group even at one rank.  (chromosome3d_a
 
 A "step" is one SA step (force evaluation + coordinate update) of every replica on the GPU.
 The timed region is exactly K steps of the real annealing schedule, starting W steps in, bracketed
-by a barrier + device synchronisation on both sides (a rank's clock stops when c3d_run_steps has synchronised the solver's
-stream; the device-wide synchronise and the closing barrier follow, and the region's time is the maximum over the ranks).  The bracket is repeated `reps` times
+by a barrier + device synchronisation on both sides (a rank's clock stops when c3d_run_steps returns: the multi-step launch has written
+its completion mark — the host watches it for `spin_wait_us`, then falls back to hipStreamSynchronize —; the device-wide synchronise and
+the closing barrier follow, and the region's time is the maximum over the ranks; `timing.value_barrier_to_barrier` is the jointly
+bracketed clock of the same regions).  The bracket is repeated `reps` times
 (consecutive K-step regions of the same schedule, the next batch of replicas starting when the
 schedule ends); `value` comes from the MEDIAN region wall time, maximum over the ranks.
 
@@ -391,7 +393,7 @@ def main():
                     s.init_replicas(M, 82364, batch * total_replicas + first)
                 want = min(left, L - pos)
                 t0 = time.perf_counter()
-                did = s.run_steps(want)                                   # synchronises the solver stream
+                did = s.run_steps(want)                                   # returns when the range is done (completion mark / stream synchronise)
                 wall += time.perf_counter() - t0
                 left -= did
                 pos += did
@@ -402,8 +404,11 @@ def main():
                 totals["sa_steps"] += did
                 totals["launches"] += la
             if timed and dist is not None:
-                # closing bracket.  A rank's clock has stopped after run_steps' synchronisation of the solver's stream — the only
-                # stream of this process with work in the region, and exactly what the one-rank line measures; the device-wide
+                # closing bracket.  A rank's clock has stopped when c3d_run_steps returned: the last workgroup of the multi-step launch has
+                # written its completion mark into host-mapped memory (c3d_api.cpp run_cluster; ~6 us before the stream retires the
+                # kernel — one-rank regions follow each other back to back, so whatever drains after the mark delays the NEXT region's
+                # launch and cannot hide) — the only stream of this process with work in the region, and exactly what the one-rank line
+                # measures; the device-wide
                 # torch.cuda.synchronize() (~4 us on an idle device) and the barrier (tens of microseconds over RCCL: a third of
                 # a 20-step region) follow.  The region's time is the MAXIMUM over the ranks (all_reduce below): the slowest
                 # rank counts, the bracket's own latency does not.
@@ -504,8 +509,10 @@ def main():
             "ms_per_step": round(1e3 * wall / args.steps, 6),
             "higher_is_better": True,
             "scaling": args.scaling,
-            **({"weak_scaling_value": round(weak_value, 1), "weak_scaling_note": f"{args.replicas} replicas per GPU, same call pattern, same run"}
-               if weak_value is not None else {}),
+            # the weak-scaling figure under ONE key in every line, whatever --scaling says (strong: measured by a second pass of the same
+            # call pattern with `--replicas` per GPU; weak: it IS `value`), so that lines of different rounds and modes stay comparable
+            "weak_scaling_value": round(weak_value if weak_value is not None else value, 1),
+            "weak_scaling_note": f"{args.replicas} replicas per GPU, same call pattern, same run",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "bundled Hi-C matrix chr1_500kb (tests/golden/inputs, exact float64 upper triangle); random-coil starts, seed 82364",

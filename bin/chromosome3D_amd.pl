@@ -59,6 +59,9 @@ print "Input      : $file_if\nOutput Dir : $dir_out\nScaling(K) : $K\nAlpha     
 print "Effective Conversion Equation is : D = $K * mean(IF^$ALPHA) / IF^$ALPHA\n";
 
 my $ID = basename($file_if, ".txt");
+# $ID names files, rides in glob() patterns and on job.sh's lines: letters, digits, '_', '.', '+', '-' only (a matrix called
+# `a$(cmd).txt`, or one with quotes, blanks or glob characters, stops here, before anything is written)
+die "ERROR! the matrix file's name may hold letters, digits, '_', '.', '+' and '-' only: '$ID'\n" unless $ID =~ /^[\w.+-]+$/;
 # the reference wipes the whole output directory (`rm -f $dir_out/*`, :56); we only remove what a
 # previous run of this driver left there
 unlink glob("$dir_out/${ID}_*.pdb"), glob("$dir_out/iam.*");
@@ -114,7 +117,7 @@ open my $job, ">", "job.sh" or die $!;
 print $job "#!/bin/bash\necho \"starting c3d_solve..\"\ntouch iam.running\n";
 # every string argument single-quoted for the shell; the residue names travel as the file written above, never as text on the line
 print $job shq($solver)." --if ".shq("$ID.txt")." --out . --id ".shq($ID)." -k ".($K+0)." -a ".($ALPHA+0)." -m ".int($MODELS)." --seed ".int($SEED)." --device ".int($DEVICE).(defined $file_seq ? " --seq ".shq("\@$ID.fasta") : "")."\n";
-print $job "if [ -f \"${ID}_${MODELS}.pdb\" ]; then\n   rm -f iam.running\n   echo \"trial structures written.\"\n   exit\nfi\n";
+print $job "if [ -f ".shq("${ID}_".int($MODELS).".pdb")." ]; then\n   rm -f iam.running\n   echo \"trial structures written.\"\n   exit\nfi\n";
 print $job "echo \"ERROR! Final structures not found!\"\nmv iam.running iam.failed 2>/dev/null || touch iam.failed\n";
 close $job;
 chmod 0755, "job.sh";

@@ -873,11 +873,15 @@ extern "C" void c3d_destroy(c3d_ctx* c) {
 
 extern "C" int c3d_set_model(c3d_ctx* c, const c3d_model* m) {
     if (!c || !m) return fail(C3D_ERR_INVALID, "c3d_set_model: null argument");
-    if (m->mass <= 0 || m->rswitch <= 0 || m->min_sep < 1 || m->rep_sep < 1 || m->rep_sep > 3 || m->noe_pot < 0 || m->noe_pot > 3 || m->mrswitch <= 0 || (m->msoexp != 1 && m->msoexp != 2))
+    // msoexp (the struct's last member, added in round 4) = 0 means "the default, 2": a caller that zero-initialises the struct and
+    // fills in what it knows keeps working ("ABI notes")
+    const int msoexp = m->msoexp == 0 ? 2 : m->msoexp;
+    if (m->mass <= 0 || m->rswitch <= 0 || m->min_sep < 1 || m->rep_sep < 1 || m->rep_sep > 3 || m->noe_pot < 0 || m->noe_pot > 3 || m->mrswitch <= 0 || (msoexp != 1 && msoexp != 2))
         return fail(C3D_ERR_INVALID, "c3d_set_model: parameter out of range");
     if (c->have_targets && m->min_sep != c->model.min_sep)
         return fail(C3D_ERR_INVALID, "c3d_set_model: min_sep must be set before the targets are built");
     c->model = *m;
+    c->model.msoexp = msoexp;
     dev_free(c->buf.tgs2);                 // the pre-scaled pair targets of the per-step kernel carry 1 / mrs: rebuilt on demand
     build_program(c);
     if (c->precision == 64 && c->b64.T) return build_targets64(c);     // the fp64 target matrix encodes "no restraint" per potential

@@ -10,6 +10,9 @@
 //
 //   c3d_batch <dir with *_matrix.txt | matrix files...> --out <root> [--devices <all>] [--lanes 3] [-m 20] [-k 11] [-a 0.5]
 //             [--seed 82364] [--min-steps 3000] [--gtol 1e-2] [--pattern _500kb_]
+//             [--map-devices-to P]   rehearsal hook: every logical device 0 .. N-1 of --devices N is physical device P (the per-device
+//                                    LPT lists, threads and contexts of an N-GPU node on a box with fewer GPUs; anneals are serialised
+//                                    per PHYSICAL device, so the models are what --devices 1 gives; its timings mean nothing)
 // Output: <root>/<chromosome>/ with the files a reference run leaves (<ID>.dist, .rr, contact.tbl, model_info.log,
 // <ID>_model1..5.pdb, <ID>_<k>.pdb) and <root>/<chromosome>.log with the satisfaction table; one summary line per matrix.
 #include <dirent.h>
@@ -204,7 +207,7 @@ int main(int argc, char** argv) {
     Options o;
     std::vector<std::string> inputs;
     std::string pattern;
-    int devices = -1, lanes = 3;
+    int devices = -1, lanes = 3, map_to = -1;
     for (int a = 1; a < argc; ++a) {
         const std::string s = argv[a];
         auto next = [&](const char* what) -> const char* {
@@ -213,6 +216,7 @@ int main(int argc, char** argv) {
         };
         if (s == "--out" || s == "-o") o.out = next("--out");
         else if (s == "--devices") devices = atoi(next("--devices"));
+        else if (s == "--map-devices-to") map_to = atoi(next("--map-devices-to"));
         else if (s == "--lanes") lanes = std::max(1, std::min(4, atoi(next("--lanes"))));
         else if (s == "-m") o.models = atoi(next("-m"));
         else if (s == "-k") o.K = atof(next("-k"));
@@ -222,7 +226,7 @@ int main(int argc, char** argv) {
         else if (s == "--gtol") o.gtol = atof(next("--gtol"));
         else if (s == "--pattern") pattern = next("--pattern");
         else if (s == "--violations") o.violations = true;
-        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text] [--violations]\n"); return 0; }
+        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text] [--violations] [--map-devices-to P (rehearsal)]\n"); return 0; }
         else inputs.push_back(s);
     }
     if (o.out.empty() || inputs.empty() || o.models < 1) { fprintf(stderr, "c3d_batch: need input matrices and --out <root> (see --help)\n"); return 2; }
@@ -231,7 +235,9 @@ int main(int argc, char** argv) {
     if (jobs.empty()) { fprintf(stderr, "c3d_batch: no *_matrix.txt found\n"); return 2; }
     const int ndev = c3d_device_count();
     if (ndev < 1) { fprintf(stderr, "c3d_batch: no HIP device visible: libc3d has no CPU fallback\n"); return 1; }
-    if (devices < 1 || devices > ndev) devices = ndev;
+    if (map_to >= ndev) { fprintf(stderr, "c3d_batch: --map-devices-to %d: this machine has %d device(s)\n", map_to, ndev); return 2; }
+    if (map_to >= 0) { if (devices < 1) devices = 1; if (devices > 64) devices = 64; }
+    else if (devices < 1 || devices > ndev) devices = ndev;
     mkdir(o.out.c_str(), 0755);
     // longest-processing-time-first: biggest job to the least loaded GPU
     std::vector<size_t> order(jobs.size());
@@ -258,7 +264,8 @@ int main(int argc, char** argv) {
       for (int lane = 0; lane < lanes; ++lane)
         workers.emplace_back([&, g]() {
             c3d_ctx* ctx = nullptr;
-            if (c3d_create(g, &ctx) != C3D_OK) {     // this lane only: the GPU's other lanes take its jobs (see below if none came up)
+            const int phys = map_to >= 0 ? map_to : g;   // (rehearsal: all logical devices on one physical one)
+            if (c3d_create(phys, &ctx) != C3D_OK) {     // this lane only: the GPU's other lanes take its jobs (see below if none came up)
                 std::lock_guard<std::mutex> lk(g_print);
                 fprintf(stderr, "c3d_batch: GPU %d: %s\n", g, c3d_last_error());
                 return;
@@ -268,7 +275,7 @@ int main(int argc, char** argv) {
                 const size_t at = next_job[g]++;
                 if (at >= mine[g].size()) break;
                 Job& job = jobs[mine[g][at]];
-                job.ok = solve_one(ctx, o, job, gpu_mu[g]);
+                job.ok = solve_one(ctx, o, job, gpu_mu[map_to >= 0 ? 0 : g]);   // one anneal at a time per PHYSICAL device
                 std::lock_guard<std::mutex> lk(g_print);
                 if (job.ok) printf("%s\n", job.summary.c_str());
                 else { printf("FAILED: %s (%s)\n", job.chrom.c_str(), job.summary.c_str()); ++failed; }

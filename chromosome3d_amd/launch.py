@@ -15,9 +15,20 @@ RCCL code path (init, device-side all_gather / all_reduce) also runs on a one-GP
 Rehearsal with fewer GPUs than ranks: C3D_BENCH_BACKEND=gloo (ranks share the devices there are).
 """
 import os
+import re
 import socket
 import subprocess
 import sys
+
+# Lines of the children's stdout that are library chatter, not output of ours: gloo's connection banner ("[Gloo] Rank 0 is connected to 1
+# peer ranks ..."), c10d / torchrun log records ("[W1005 ...", "W1005 03:52:...", "[rank0]:[W...") and RCCL's "NCCL INFO/WARN" lines.
+# Only these go to stderr; everything else a rank prints — rank 0's JSON line, the batch driver's per-chromosome table — is relayed on
+# stdout, where `python -m chromosome3d_amd.batch --gpus N > out.txt` expects it (as the one-rank path prints it).
+_CHATTER = re.compile(r"^\s*(\[Gloo\]|\[(W|E|I)\d{4} |(W|E|I)\d{4} \d\d:|\[rank\d+\]:\[|[\w.-]+:\d+:\d+ \[\d+\] NCCL |NCCL (INFO|WARN))")
+
+
+def is_chatter(line):
+    return bool(_CHATTER.match(line))
 
 
 def free_port():
@@ -79,8 +90,8 @@ def ensure_ranks(gpus, argv, script=None, module=None, what="bench.py"):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout:                                # rank 0's JSON line comes through here; library chatter
-        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr      # ("[Gloo] Rank 0 is connected ...") goes to stderr
+    for line in proc.stdout:                                # what the ranks print comes through here; library chatter goes to stderr
+        out = sys.stderr if is_chatter(line) else sys.stdout
         out.write(line)
         out.flush()
     sys.exit(proc.wait())

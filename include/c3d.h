@@ -59,10 +59,11 @@ typedef struct {
     float masym;       /* noe_pot 3: asymptote slope of the lower side (CNS masymptote)  */
     float mrswitch;    /* noe_pot 3: the lower side is square up to t - d = mrswitch     */
     int32_t msoexp;    /* noe_pot 3: exponent of the lower side's soft form a + b / D^msoexp + masym D beyond mrswitch
-                          (CNS msoexponent), 1 or 2.  Shipped: mrswitch 10, masym 0, msoexp 2 — X-PLOR's own defaults
+                          (CNS msoexponent), 1 or 2; 0 = the default (2).  Shipped: mrswitch 10, masym 0, msoexp 2 — X-PLOR's own defaults
                           (rswitch 10, asymptote 0, soexponent 2), which the deck never overrides for the minus side:
                           the push on a pair far inside its target rises to 2 S mrswitch and then DECAYS as D^-3     */
-} c3d_model;
+} c3d_model;   /* ABI: no size / version member — every caller fills the struct through c3d_default_model of the library it links (the Perl
+                  binding, c3d_solve, c3d_batch and the ctypes mirror do); `msoexp` was appended in round 4 ("ABI notes") */
 
 /* One stage of the annealing schedule (defaults: c3d_default_schedule, which restates
  * chromosome3D.pl:1631-1700 hot stages, :1729-1782 slow cool, :1790-1803 minimisation). */
@@ -129,7 +130,8 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *   cluster_num_xcc, cluster_inject_incomplete, resident_inject_timeout   test hooks of the cluster kernel's safety net
  *                   (a device that does not expose 8 XCDs gets no cluster plan; a launch that ends without its completion
  *                   mark or with a time-out is re-run on the per-step path)
- *   precision       32 (default) or 64: the fp64 reference kernels (c3d_f64.hip); call before c3d_init_replicas
+ *   precision       32 (default) or 64: the fp64 reference kernels (c3d_f64.hip); call before c3d_init_replicas.  The fp64 step stages a
+ *                   replica's coordinates in LDS: at most 2560 beads (c3d_init_replicas returns C3D_ERR_INVALID beyond; fp32: 8192)
  *   symmetric       1: symmetric-tile kernels for large N (c3d_sym.hip; opt-in); call before c3d_init_replicas
  *   eval_rows_per_wave  4 (default) / 2 / -2: form of the forces hook (c3d_eval_forces) — four rows per wave with the scalar pair term; 2 = two
  *                   rows per wave, the step kernels' code (shipped potential: the packed pair term); -2 = two rows per wave, scalar pair

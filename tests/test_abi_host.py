@@ -148,6 +148,8 @@ def test_violation_rows_equal_printf_formatting(built, tmp_path):
     total = 0
     for trial, scale in enumerate((2.0, 30.0, 900.0, 5.0)):
         x = (rng.normal(size=(n, 3)) * scale).astype(np.float32)
+        if scale > 100:
+            x = np.abs(x)            # four-digit coordinates as a PDB can hold them: -999.999 .. 9999.999 (anything else is refused, below)
         if trial == 3:
             x = (np.round(x * 2000) / 2000).astype(np.float32)
         R = 4000
@@ -376,3 +378,36 @@ def test_residue_names_follow_an_installed_sequence(built, tmp_path):
         pipeline.set_residue_sequence(None)
     pipeline.write_pdb(p, xyz[:5])
     assert [l[17:20] for l in open(p) if l.startswith("ATOM")] == ["MET"] * 5
+
+
+def test_host_helpers_refuse_coordinates_a_pdb_cannot_hold(tmp_path):
+    """Round 4's review: non-finite or huge coordinates went through round_dec3 and an out-of-range float -> integer conversion and came
+    back as C3D_OK with rows like `-9223372036854776.32`.  Every public host helper that takes coordinates now returns C3D_ERR_INVALID
+    with a message naming the bead — and writes nothing (tools/sanitize/run.sh drives the same under ASan + UBSan float-cast-overflow)."""
+    from chromosome3d_amd import lib, pipeline
+    rng = np.random.default_rng(5)
+    n = 40
+    good = (rng.normal(size=(n, 3)) * 10).astype(np.float32)
+    ri, rj, rt = np.array([1, 2, 3], dtype=np.int32), np.array([10, 20, 30], dtype=np.int32), np.array([50, 60, 70], dtype=np.int32)
+    IF = np.abs(rng.normal(size=(n, n))) + 1.0
+    IF = IF + IF.T
+    for bad in (np.inf, -np.inf, np.nan, 1e30, -1e30, 1e7, 10000.0, -1000.0):
+        x = good.copy()
+        x[6, 2] = bad
+        out = tmp_path / "v.txt"
+        for call in (lambda: pipeline.write_violations(x, (ri, rj, rt), str(out)), lambda: pipeline.assess(x, (ri, rj, rt)),
+                     lambda: pipeline.write_pdb(str(tmp_path / "m.pdb"), x), lambda: pipeline.spearman_IF_pdb(IF, x),
+                     lambda: pipeline.spearman_IF_models(IF, np.stack([good, x]))):
+            with pytest.raises(lib.C3DError) as ei:
+                call()
+            assert "error -1" in str(ei.value) and ("bead 7" in str(ei.value) or "bead 47" in str(ei.value)), str(ei.value)
+        assert not out.exists() and not (tmp_path / "m.pdb").exists()
+    with pytest.raises(lib.C3DError):
+        pipeline.model_similarity(np.where(np.arange(3 * n).reshape(n, 3) == 5, np.nan, good.astype(np.float64)), good)
+    # the edge of the range is still taken, and fits its columns
+    x = good.copy()
+    x[0] = (9999.999, -999.999, 0.0)
+    pipeline.write_pdb(str(tmp_path / "edge.pdb"), x)
+    row = [l for l in open(tmp_path / "edge.pdb") if l.startswith("ATOM")][0]
+    assert row[30:54] == "9999.999-999.999   0.000"
+    assert np.allclose(pipeline.read_pdb_ca(str(tmp_path / "edge.pdb"))[0], x[0])

@@ -226,3 +226,34 @@ def test_batch_executor_lanes_do_not_change_results(built, tmp_path):
     assert flags == sorted(flags, reverse=True) and set(flags) <= {"  1", "  0"}
     table = lambda d: [l for l in open(d / "chr21_1mb.log").read().splitlines() if "/528" in l]
     assert len(table(od)) == 6 and table(od) == table(outs[0])
+
+
+@pytest.mark.gpu
+def test_batch_executor_per_device_lists_and_threads_rehearsed_on_one_gpu(built, tmp_path):
+    """c3d_batch --devices N on an N-GPU node (csrc/c3d_batch_main.cpp: LPT over the devices, `lanes` host threads and contexts per
+    device) had never executed with N > 1: `--map-devices-to 0` runs that code on this box — four logical devices, two lanes each, all on
+    physical device 0 — and the models equal those of `--devices 1` byte for byte; every logical device got work."""
+    import re
+    exe = os.path.join(LIBDIR, "c3d_batch")
+    ind = os.path.join(GOLD, "inputs")
+    mats = [os.path.join(ind, f"{c}_matrix.txt") for c in ("chr21_1mb", "chr22_1mb")]
+    from tests.util import write_if_text
+    for c in ("chr20_1mb", "chr13_1mb", "chr19_500kb", "chr21_500kb"):          # packed fixtures -> the reference's text format
+        pth = tmp_path / f"{c}_matrix.txt"
+        write_if_text(load_if(c), pth)
+        mats.append(str(pth))
+    runs = {}
+    for tag, extra in (("one", ["--devices", "1", "--lanes", "1"]), ("four", ["--devices", "4", "--lanes", "2", "--map-devices-to", "0"])):
+        od = tmp_path / tag
+        p = subprocess.run([exe] + mats + ["--out", str(od), "-m", "6"] + extra, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "6 matrices x 6 models" in p.stdout and "0 failed" in p.stdout
+        runs[tag] = (od, p.stdout)
+    assert "on 4 GPU(s), 2 lane(s) each" in runs["four"][1]
+    assert sorted(set(re.findall(r"GPU (\d)  \[phases", runs["four"][1]))) == ["0", "1", "2", "3"]      # every logical device took jobs
+    for chrom in ("chr21_1mb", "chr22_1mb", "chr20_1mb", "chr13_1mb", "chr19_500kb", "chr21_500kb"):
+        cid = chrom + "_matrix"
+        for k in range(1, 6):
+            assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["four"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
+    bad = subprocess.run([exe] + mats[:1] + ["--out", str(tmp_path / "x"), "--map-devices-to", "7"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "--map-devices-to 7" in bad.stderr

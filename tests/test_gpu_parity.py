@@ -885,3 +885,26 @@ print("HASH", " ".join(h))
         assert p.returncode == 0, p.stderr[-2000:]
         out.append([l for l in p.stdout.splitlines() if l.startswith("HASH")][-1].split()[1:])
     assert out[0] == out[1] and int(out[0][1]) >= 1 and len(set(out[0][i] for i in (0, 2, 3))) == 3
+
+
+def test_model_struct_with_a_zero_last_member_means_the_default(solver):
+    """c3d_model has no size / version member and round 4 appended `msoexp`: a caller that zero-initialises the struct and fills in the
+    members it knows passes msoexp = 0, which must mean the default (2), not "parameter out of range" (advisor, round 4)."""
+    from chromosome3d_amd import default_model, lib
+    IF = load_if("chr21_1mb")
+    from chromosome3d_amd import pipeline
+    out = []
+    for mso in (2, 0):
+        m = default_model()
+        m.msoexp = mso
+        solver.set_model(m)
+        pipeline.IF2dist_new(solver, IF)
+        solver.init_replicas(3, 82364, 0)
+        F, e = solver.eval(1.0, 1.0, 0.85)
+        out.append((F.copy(), e.copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    m = default_model()
+    m.msoexp = 3
+    with pytest.raises(lib.C3DError):
+        solver.set_model(m)
+    solver.set_model(default_model())

@@ -129,3 +129,103 @@ def test_chromosome_sharded_batch_world2():
     assert batch.job_costs(m)[0] == 450 * 451 // 2 and batch.job_costs(m)[1] == 474 * 475 // 2
     from chromosome3d_amd import sharding
     assert sharding.lpt_assign(batch.job_costs(m), 8)[0][0] == 1          # the biggest job opens rank 0's list
+
+
+# ---- the EIGHT-rank line, rehearsed ---------------------------------------------------------------------
+# Nothing above two ranks had ever executed.  bench.py's main() itself runs here on eight gloo ranks with tests/standin_solver.py in
+# the solver's place: the 3,3,3,3,2,2,2,2 split, the max-over-ranks all_reduce of the region clocks, the 8-way variable-length gather
+# and the ranking of 20 models, the weak pass, and the config-4 block (23 chromosomes by LPT over 8 ranks, one gather, per-chromosome
+# ranking on rank 0).  The real solver runs the same code at four ranks on the GPU box (tests/test_bench_contract.py).
+def _bench_rank(rank, world, port, q):
+    import io
+    from contextlib import redirect_stdout
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      C3D_BENCH_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    import chromosome3d_amd
+    from tests.standin_solver import StandinSolver
+    chromosome3d_amd.Solver = StandinSolver
+    import bench
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "20", "--warmup", "5", "--reps", "3", "--no-cpu-baseline"]
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main()
+    q.put((rank, buf.getvalue()))
+
+
+def test_bench_line_at_eight_ranks():
+    import json
+    import torch.multiprocessing as mp
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_rank, args=(r, 8, port, q)) for r in range(8)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=600) for _ in range(8))
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert all(res[r].strip() == "" for r in range(1, 8))                  # ONE line, from rank 0
+    lines = [l for l in res[0].splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 20 and d["warmup"] == 5
+    assert d["config"]["replicas_per_gpu"] == [3, 3, 3, 3, 2, 2, 2, 2] and d["models_ranked"] == 20
+    assert "20 replicas of chr1_500kb in all: 3+3+3+3+2+2+2+2 per GPU, strong scaling" in d["metric"]
+    assert d["collective"] == {"backend": "gloo", "device": "cpu", "world": 8}
+    assert d["value"] > 0 and d["weak_scaling_value"] > 0 and "160" not in d["metric"]
+    assert d["roofline"]["algorithmic_bytes_per_sa_step"] == 3 * (4 * 101426 + 72 * 455)      # rank 0's GPU: its 3 replicas
+    c4 = d["config4"]
+    assert c4["chromosomes_ranked"] == 23 and len(c4["per_rank"]) == 8 and sum(r["chromosomes"] for r in c4["per_rank"]) == 23
+    assert c4["workload"].startswith("23 chromosomes at 500 kb x 20 replicas (460 models), LPT over 8 rank(s)") and c4["standins"] == ["chr2_500kb"]
+    loads = sorted(r["restraints"] for r in c4["per_rank"])
+    assert loads[-1] == 474 * 475 // 2 and loads[0] >= 0.6 * loads[-1]       # the largest job (the chr2_500kb stand-in) alone on its rank
+    # what rank 0 ranks is what one process would rank: the stand-in's energies are a function of (bead count, replica id) alone
+    from tests.standin_solver import StandinSolver
+    s = StandinSolver()
+    s.n = 455
+    s.init_replicas(20, 82364, 0)
+    e = s.energies()[:, 0]
+    assert abs(d["e_noe_best"] - round(float(e[sorted(range(20), key=lambda k: (int(e[k]), k))[0]]), 1)) < 0.06
+
+
+def _batch_main_rank(rank, world, port, q):
+    import io
+    from contextlib import redirect_stdout
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), C3D_BENCH_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    from chromosome3d_amd import batch
+    from tests.standin_solver import StandinSolver
+    batch.Solver = StandinSolver
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        batch.main(["--json"] + (["--gpus", str(world)] if world > 1 else []))
+    q.put((rank, buf.getvalue()))
+
+
+def test_batch_driver_at_eight_ranks_equals_one_rank():
+    """python -m chromosome3d_amd.batch --gpus 8 --json (main() itself, stand-in solver): 23 chromosomes once each, the per-chromosome
+    ranking rank 0 prints after the 8-way gather equals the one-process result."""
+    import json
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    outs = {}
+    for world in (1, 8):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_batch_main_rank, args=(r, world, port, q)) for r in range(world)]
+        [p.start() for p in procs]
+        res = dict(q.get(timeout=600) for _ in range(world))
+        [p.join(120) for p in procs]
+        assert all(p.exitcode == 0 for p in procs)
+        assert all(res[r].strip() == "" for r in range(1, world))
+        outs[world] = json.loads([l for l in res[0].splitlines() if l.startswith("{")][-1])
+    a, b = outs[1], outs[8]
+    assert a["world"] == 1 and b["world"] == 8 and len(a["chromosomes"]) == 23 and a["standins"] == b["standins"] == ["chr2_500kb"]
+    assert a["chromosomes"] == b["chromosomes"] and all(len(c["order"]) == 20 for c in b["chromosomes"].values())
