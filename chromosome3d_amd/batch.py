@@ -62,30 +62,76 @@ def job_costs(mats):
     return [(m.shape[0] - 5) * (m.shape[0] - 4) // 2 for m in mats.values()]
 
 
-def solve_assigned(solver, mats, mine, models=20, seed=82364, min_steps=3000, gtol=1e-2, out=None, on_job=None):
+PAIR_MAX_BEADS = 270      # a four-XCD geometry exists up to 288 beads (5 replicas per XCD x 6 workgroups of 48 rows); it pays up to ~270 (profiles/r05_config4_paired_anneals.txt: N = 287 anneals in 16.3 ms on half a device, 13.2 on all of it)
+
+
+def _prepare(solver, IF, models, seed, min_steps, gtol, xcds):
+    solver.set_option("cluster_xcd_base", 0)
+    solver.set_option("cluster_xcd_count", xcds)
+    solver.set_model(default_model())
+    d10 = pipeline.IF2dist_new(solver, IF)
+    solver.set_schedule(default_schedule(min_steps), None, gtol, 250)
+    solver.init_replicas(models, seed, 0)
+    return d10
+
+
+def solve_assigned(solver, mats, mine, models=20, seed=82364, min_steps=3000, gtol=1e-2, out=None, on_job=None, second=None):
     """Solve the chromosomes with indices `mine`; returns records [len(mine) * models, 5]:
-    chromosome index, replica, E_noe, Spearman(IF, d), anneal ms.  on_job(cid, solver) is called after every anneal (bookkeeping hooks)."""
+    chromosome index, replica, E_noe, Spearman(IF, d), anneal ms.  on_job(cid, solver) is called after every anneal (bookkeeping hooks).
+    `second` = another context on the same GPU: two consecutive chromosomes of at most PAIR_MAX_BEADS beads then anneal SIDE BY SIDE, one on
+    XCDs 0-3, the other on XCDs 4-7 (options cluster_xcd_count / cluster_xcd_base; test.sh:9-12 runs its 23 jobs concurrently) — same
+    models bit for bit, 1.4-1.8 x for such a pair (profiles/r05_config4_paired_anneals.txt); everything else runs as before."""
+    import threading
     cids = list(mats)
     recs = []
-    for k in mine:
+
+    def collect(s, k, d10):
         cid, IF = cids[k], mats[cids[k]]
-        solver.set_model(default_model())
-        d10 = pipeline.IF2dist_new(solver, IF)
-        solver.set_schedule(default_schedule(min_steps), None, gtol, 250)
-        solver.init_replicas(models, seed, 0)
-        solver.run()
         if on_job:
-            on_job(cid, solver)
-        x, e = solver.coords(), solver.energies()
-        rho = solver.score(IF)[2]           # K6 on the device, from the resident coordinates (= pipeline.spearman_IF_models(IF, x) to rounding)
+            on_job(cid, s)
+        x, e = s.coords(), s.energies()
+        rho = s.score(IF)[2]                # K6 on the device, from the resident coordinates (= pipeline.spearman_IF_models(IF, x) to rounding)
         r = np.zeros((models, 5))
-        r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4] = k, np.arange(models), e[:, 0], rho, solver.last_timing()[0]
+        r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4] = k, np.arange(models), e[:, 0], rho, s.last_timing()[0]
         recs.append(r)
         if out:
             d = os.path.join(out, cid)
             os.makedirs(d, exist_ok=True)
             pipeline.write_front_half(d10, d, f"{cid}_matrix")
             pipeline.assess_dgsa(d, f"{cid}_matrix", x, e, pipeline.restraints_from_dist10(d10), quiet=True)
+
+    queue = list(mine)
+    small = lambda k: mats[cids[k]].shape[0] <= PAIR_MAX_BEADS
+    while queue:
+        k = queue.pop(0)
+        if second is not None and queue and small(k) and small(queue[0]):
+            k2 = queue.pop(0)
+            da = _prepare(solver, mats[cids[k]], models, seed, min_steps, gtol, 4)
+            db = _prepare(second, mats[cids[k2]], models, seed, min_steps, gtol, 4)
+            if solver.stat("cluster_ok") and second.stat("cluster_ok"):
+                second.set_option("cluster_xcd_base", 4)
+                err = []
+
+                def other():
+                    try:
+                        second.run()
+                    except Exception as ex:      # surfaces in the caller's thread
+                        err.append(ex)
+                th = threading.Thread(target=other)
+                th.start()
+                solver.run()
+                th.join()
+                if err:
+                    raise err[0]
+                collect(solver, k, da)
+                collect(second, k2, db)
+                continue
+            queue.insert(0, k2)                   # no four-XCD geometry for one of them: one after the other, whole device
+        d10 = _prepare(solver, mats[cids[k]], models, seed, min_steps, gtol, 8)
+        solver.run()
+        collect(solver, k, d10)
+    order = {k: i for i, k in enumerate(mine)}
+    recs.sort(key=lambda r: order[int(r[0, 0])])
     return np.concatenate(recs) if recs else np.zeros((0, 5))
 
 
@@ -114,7 +160,7 @@ def rank_per_chromosome(rec, n_chrom):
     return out
 
 
-def bench_block(s, rank, world, dist, device, sync_all=None, inputs=None):
+def bench_block(s, rank, world, dist, device, sync_all=None, inputs=None, pair=True):
     """The `config4` block of a bench.py line: all 23 chromosomes at 500 kb x 20 replicas (test.sh:9-12; chr2_500kb is the documented
     stand-in), matrices to ranks by longest-processing-time-first on their restraint counts, every rank solves its share through the C
     ABI (full default schedule with the gradient exit, scoring included), ONE gather of the model records, per-chromosome ranking on rank
@@ -126,11 +172,16 @@ def bench_block(s, rank, world, dist, device, sync_all=None, inputs=None):
     mats = load_matrices(inputs or os.path.join(root, "tests", "golden", "all45"), "_500kb", standins)
     costs = job_costs(mats)
     mine = sharding.lpt_assign(costs, world)[rank]
+    s2 = type(s)(s.device) if pair else None                # a second context on this rank's GPU: small chromosomes anneal in pairs
     solve_assigned(s, mats, mine[:1], 20)                  # first touch of this path (buffers of the largest job), untimed
+    if s2 is not None:
+        solve_assigned(s2, mats, mine[-1:], 20)
     sync_all()
     t0 = time.perf_counter()
-    rec = solve_assigned(s, mats, mine, 20)
+    rec = solve_assigned(s, mats, mine, 20, second=s2)
     t_solve = time.perf_counter() - t0
+    if s2 is not None:
+        s2.close()
     allrec = gather(rec, dist, device)
     sync_all()
     wall = time.perf_counter() - t0
@@ -142,8 +193,9 @@ def bench_block(s, rank, world, dist, device, sync_all=None, inputs=None):
     return {"workload": f"{len(mats)} chromosomes at 500 kb x 20 replicas ({len(allrec)} models), LPT over {world} rank(s), one gather",
             "wall_s": round(wall, 4), "models_per_s": round(len(allrec) / wall, 1), "standins": sorted(standins),
             "per_rank": [{"chromosomes": int(l[0]), "restraints": int(l[1]), "solve_s": round(float(l[2]), 4), "anneal_device_ms": round(float(l[3]), 2)} for l in loads],
-            "chromosomes_ranked": len(per), "spearman_best_ranked_mean": round(-float(np.mean([r[0, 3] for r in per])), 4),
-            "note": "solve_s = the rank's wall for its chromosomes (K1, 5172-step schedule with gradient exit, read-back, Spearman of 20 models each); "
+            "paired_small_anneals": bool(pair), "chromosomes_ranked": len(per), "spearman_best_ranked_mean": round(-float(np.mean([r[0, 3] for r in per])), 4),
+            "note": "paired_small_anneals: two consecutive chromosomes of <= 270 beads anneal side by side on disjoint halves of the GPU's XCDs (two contexts); "
+                    "solve_s = the rank's wall for its chromosomes (K1, 5172-step schedule with gradient exit, read-back, Spearman of 20 models each); "
                     "wall_s = barrier to barrier incl. the gather; the reference runs this as 23 background processes (test.sh:9-12)"}
 
 
@@ -159,6 +211,7 @@ def main(argv=None):
     ap.add_argument("--json", action="store_true", help="one JSON line with the per-chromosome ranking instead of the table")
     ap.add_argument("--gpus", type=int, default=0, help="ranks = GPUs (0: WORLD_SIZE if set, else 1); > 1 without WORLD_SIZE starts them")
     ap.add_argument("--dist", action="store_true", help="initialise the process group even at one rank (RCCL path on a one-GPU box)")
+    ap.add_argument("--pair", type=int, default=1, help="1 (default): small chromosomes anneal in pairs on disjoint XCD halves of the rank's GPU; 0: one at a time")
     ap.add_argument("--bench-block", action="store_true", help="print bench.py's `config4` block (one JSON line) and nothing else")
     args = ap.parse_args(argv)
 
@@ -169,7 +222,7 @@ def main(argv=None):
     dist, device, local = launch.init_process_group(local, world, force=args.dist)
     if args.bench_block:
         s = Solver(local)
-        blk = bench_block(s, rank, world, dist, device, (lambda: dist.barrier()) if dist is not None else None, args.inputs)
+        blk = bench_block(s, rank, world, dist, device, (lambda: dist.barrier()) if dist is not None else None, args.inputs, pair=bool(args.pair))
         s.close()
         if rank == 0:
             print(json.dumps(blk), flush=True)
@@ -184,10 +237,13 @@ def main(argv=None):
         sys.exit(f"no matrices matching {args.pattern!r} under {args.inputs}")
     mine = sharding.lpt_assign(job_costs(mats), world)[rank]
     s = Solver(local)
+    s2 = Solver(local) if args.pair else None
     t1 = time.perf_counter()
-    rec = solve_assigned(s, mats, mine, args.models, args.seed, args.min_steps, out=args.out)
+    rec = solve_assigned(s, mats, mine, args.models, args.seed, args.min_steps, out=args.out, second=s2)
     t_solve = time.perf_counter() - t1
     s.close()
+    if s2 is not None:
+        s2.close()
     rec = gather(rec, dist, device)
     if rank == 0:
         per = rank_per_chromosome(rec, len(mats))

@@ -144,6 +144,7 @@ struct c3d_ctx {
     int num_cus = 0, num_xcc = 0;
     int cluster_late = -1;                 // measurement knob: 0 = the tile sums always travel with the rows; -1 = planner's choice
     int cluster_geom = 0;                  // measurement knob: 100 CW + 10 RPW + helpers forces that cluster geometry (0 = planner's choice)
+    int xcd_base = 0, xcd_count = 8;       // the XCDs a multi-step launch of this context lives on (options cluster_xcd_base / cluster_xcd_count)
     bool inject_misplaced = false;         // test hook: workgroup 0 of the next cluster launch reports a wrong XCD
     bool static_place = true;              // cluster launches number the workgroups of an XCD as blockIdx / 8 (verified in the kernel)
     int placement_mismatches = 0;
@@ -172,8 +173,22 @@ struct c3d_ctx {
     size_t d_score_bytes = 0;
     size_t h_stage_bytes = 0;
     std::thread preload;                   // loads the code objects of the job's kernels while the caller is busy on the host (c3d_create)
+    // The IF side of the Spearman coefficient (average ranks of the matrix's ordered pairs: a radix sort of up to 2 x 10^5 records, 5 ms at
+    // N = 455) depends on the INPUT alone: c3d_set_if_matrix starts it on a helper thread over a copy of the matrix, and c3d_score_replicas
+    // — which comes after the anneal — takes the result when its IF argument holds the same numbers (memcmp), else computes as before.
+    struct IfRanks {
+        std::thread worker;
+        std::vector<double> matrix, rank;  // the copy the worker reads; rank_matrix of if_pair_ranks
+        size_t m = 0;
+        double mean = 0, saa = 0;
+        int n = 0, range = 0;
+        bool valid = false;
+        void join() { if (worker.joinable()) worker.join(); }
+    } ifr;
+    int prefetch_ranks = 1;                // option prefetch_ranks: 0 = no helper thread (measurement knob)
     unsigned* h_tmo_dev = nullptr;         // its device address
 
+    long rank_prefetch_hits = 0;
     long k1_recomputed = 0, k1_patched = 0;   // K1: near-tie elements redone on the host in the reference's order / changed by it
     long graph_captures = 0, graph_launches = 0, step_launches = 0, resident_launches = 0, cluster_launches = 0;
     int last_path = 0;                     // 0 per-step, 2 k_cluster, 3 fp64 reference (what the last run_ops used)
@@ -484,6 +499,7 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     if (c->inject_incomplete) { ++pl.expected; c->inject_incomplete = false; }
     if (c->kernel_timing) { pl.t0 = c->kev0; pl.t1 = c->kev1; }
     pl.static_place = c->static_place ? (c->inject_misplaced ? 2 : 1) : 0;
+    pl.xcd_base = c->xcd_base;
     c->inject_misplaced = false;
     c->h_tmo[2] = 0;
     const auto h0 = std::chrono::steady_clock::now();
@@ -849,6 +865,7 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
 extern "C" void c3d_destroy(c3d_ctx* c) {
     if (!c) return;
     if (c->preload.joinable()) c->preload.join();
+    c->ifr.join();
     hipSetDevice(c->device);
     for (int g = 0; g < c3d_ctx::kMaxGroups; ++g) if (c->gstream[g]) hipStreamSynchronize(c->gstream[g]);
     drop_graphs(c);
@@ -950,6 +967,17 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
     if (!strcmp(key, "cluster_static_placement")) { c->static_place = value != 0; c->inject_misplaced = value == 2; return C3D_OK; }   // 0: per-XCD atomic slot counters; 2: test hook
     if (!strcmp(key, "cluster_inject_incomplete")) { c->inject_incomplete = value != 0; return C3D_OK; }   // test hook
     if (!strcmp(key, "cluster_num_xcc")) { c->num_xcc = (int)value; free_replica_buffers(c); return C3D_OK; }   // test hook: pretend a partitioned device
+    if (!strcmp(key, "prefetch_ranks")) { c->prefetch_ranks = value != 0; return C3D_OK; }
+    if (!strcmp(key, "cluster_xcd_count")) {      // 1..8 XCDs for this context's multi-step launches; re-plans: before c3d_init_replicas
+        const int v = (int)value;
+        if (v < 1 || v > 8 || c->xcd_base + v > 8) return fail(C3D_ERR_INVALID, "cluster_xcd_count: 1..8, and cluster_xcd_base + cluster_xcd_count <= 8");
+        c->xcd_count = v; free_replica_buffers(c); return C3D_OK;
+    }
+    if (!strcmp(key, "cluster_xcd_base")) {       // first XCD of the set; may change between launches (the plan depends on the count only)
+        const int v = (int)value;
+        if (v < 0 || v + c->xcd_count > 8) return fail(C3D_ERR_INVALID, "cluster_xcd_base: 0 .. 8 - cluster_xcd_count");
+        c->xcd_base = v; return C3D_OK;
+    }
     if (!strcmp(key, "cluster_late_tiles")) { c->cluster_late = value != 0 ? -1 : 0; free_replica_buffers(c); return C3D_OK; }   // measurement knob: 0 = never; before c3d_init_replicas
     if (!strcmp(key, "cluster_geometry")) {  // measurement knob: 100 CW + 10 RPW + helpers (0 = planner); before c3d_init_replicas
         if (value < 0 || value > 1699) return fail(C3D_ERR_INVALID, "cluster_geometry = 100 compute waves + 10 rows per wave + helper waves");
@@ -979,6 +1007,20 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     free_replica_buffers(c);
     set_dims(c, n);
     const size_t nn = (size_t)n * n;
+    // the Spearman's IF ranks (range 3: spearman_IF_pdb.pl:14, the only range a driver asks for) on a helper thread, beside K1 and the anneal
+    c->ifr.join();
+    c->ifr.valid = false;
+    if (c->prefetch_ranks) {
+        try {
+            c->ifr.matrix.assign(IF, IF + nn);
+            c->ifr.n = n; c->ifr.range = 3;
+            c3d_ctx::IfRanks* const w = &c->ifr;
+            c->ifr.worker = std::thread([w] {
+                try { c3d::if_pair_ranks(w->matrix.data(), w->n, w->range, w->rank, w->m, w->mean, w->saa); w->valid = true; }
+                catch (...) { w->valid = false; }
+            });
+        } catch (...) { c->ifr.valid = false; }          // no memory or no thread: c3d_score_replicas computes the ranks itself
+    }
     DevTmp<double> dIF, dP, dpart;
     DevTmp<int32_t> ddist;
     DevTmp<unsigned char> dflags;
@@ -1113,7 +1155,7 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 HIP_TRY(hipMalloc(&c->d_sym_scratch, sizeof(float) * c3d::sym_scratch_floats(m)));
             }
-            c->cl_ok = c3d::cluster_plan(m, c->num_cus, c->num_xcc, c->cluster_geom, c->cluster_late, &c->cl_plan);
+            c->cl_ok = c3d::cluster_plan(m, c->num_cus, c->num_xcc, c->cluster_geom, c->cluster_late, c->xcd_count, &c->cl_plan);
             if (c->cl_ok) {
                 c->cl_plan.device = c->device;
                 c->crec_bytes = c3d::cluster_record_bytes(m, c->cl_plan);
@@ -1399,6 +1441,10 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     else if (!strcmp(key, "k1_recomputed")) *value = (double)c->k1_recomputed;
     else if (!strcmp(key, "k1_patched")) *value = (double)c->k1_patched;
     else if (!strcmp(key, "last_path")) *value = (double)c->last_path;
+    else if (!strcmp(key, "rank_prefetch_hits")) *value = (double)c->rank_prefetch_hits;
+    else if (!strcmp(key, "cluster_xcd_count")) *value = (double)c->xcd_count;
+    else if (!strcmp(key, "cluster_xcd_base")) *value = (double)c->xcd_base;
+    else if (!strcmp(key, "cluster_ok")) *value = c->cl_ok ? 1.0 : 0.0;
     else if (!strcmp(key, "cluster_parts")) *value = c->cl_ok ? (double)c->cl_plan.parts : 0.0;
     else if (!strcmp(key, "cluster_rows_per_wave")) *value = c->cl_ok ? (double)c->cl_plan.rpw : 0.0;
     else if (!strcmp(key, "cluster_late_tiles")) *value = c->cl_ok ? (double)c->cl_plan.late_tiles : 0.0;
@@ -1483,9 +1529,18 @@ extern "C" int c3d_score_replicas(c3d_ctx* c, const double* IF, int range, int32
     struct { unsigned* p; } d_hist{reinterpret_cast<unsigned*>(base + b_rank + b_xr + b_part)}, d_below{reinterpret_cast<unsigned*>(base + b_rank + b_xr + b_part + b_hist)};
     struct { int* p; } d_ovf{reinterpret_cast<int*>(base + b_rank + b_xr + b_part + 2 * b_hist)};
     if (IF && rho) {
-        c3d::if_pair_ranks(IF, n, range, rankA, m, ma, saa);
+        // the ranks c3d_set_if_matrix started on its helper thread, if this is the same matrix (same numbers: memcmp) and range
+        c->ifr.join();
+        const std::vector<double>* ranks = &rankA;
+        if (c->ifr.valid && c->ifr.n == n && c->ifr.range == range && c->ifr.matrix.size() == (size_t)n * n &&
+            memcmp(c->ifr.matrix.data(), IF, sizeof(double) * (size_t)n * n) == 0) {
+            ranks = &c->ifr.rank; m = c->ifr.m; ma = c->ifr.mean; saa = c->ifr.saa;
+            ++c->rank_prefetch_hits;
+        } else {
+            c3d::if_pair_ranks(IF, n, range, rankA, m, ma, saa);
+        }
         if (m < 2) return fail(C3D_ERR_INVALID, "c3d_score_replicas: range leaves no pairs");
-        HIP_TRY(hipMemcpyAsync(d_rank.p, rankA.data(), sizeof(double) * rankA.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_rank.p, ranks->data(), sizeof(double) * ranks->size(), hipMemcpyHostToDevice, c->stream));
     }
     else d_rank.p = nullptr;
     const double mb = 0.5 * ((double)m + 1.0);     // mean of the ranks 1..m, ties or not

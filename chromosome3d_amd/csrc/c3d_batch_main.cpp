@@ -10,6 +10,7 @@
 //
 //   c3d_batch <dir with *_matrix.txt | matrix files...> --out <root> [--devices <all>] [--lanes 3] [-m 20] [-k 11] [-a 0.5]
 //             [--seed 82364] [--min-steps 3000] [--gtol 1e-2] [--pattern _500kb_]
+//             [--pair 1]             1 (default): two small chromosomes anneal side by side on disjoint halves of a device's XCDs; 0: one at a time
 //             [--map-devices-to P]   rehearsal hook: every logical device 0 .. N-1 of --devices N is physical device P (the per-device
 //                                    LPT lists, threads and contexts of an N-GPU node on a box with fewer GPUs; anneals are serialised
 //                                    per PHYSICAL device, so the models are what --devices 1 gives; its timings mean nothing)
@@ -21,6 +22,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,7 +38,7 @@ namespace {
 struct Job {
     std::string path, id, chrom;
     double cost = 0;
-    int device = -1;
+    int device = -1, half = -1;    // half: which four XCDs it annealed on (-1: the whole device)
     bool ok = false;
     std::string summary;
 };
@@ -48,6 +50,37 @@ struct Options {
     bool violations = false;       // --violations: also leave contact_violation.txt (:475-483; 180 MB of text per chromosome at N = 455)
 };
 std::mutex g_print;
+bool g_pair = true;                // --pair 0: every anneal has the whole device to itself (round 4)
+
+// Who anneals where on one physical device.  The multi-step kernel places replica r on XCD base + r % count (c3d.h, option
+// cluster_xcd_count / cluster_xcd_base): a chromosome small enough for a four-XCD geometry takes ONE half of the device (XCDs 0-3 or
+// 4-7) and a second small chromosome anneals beside it on the other half — no CU is shared, the models are the same bits
+// (profiles/r05_config4_paired_anneals.txt: 1.4-1.8 x for the pairs of config 4 with N <= 287); a large one takes both halves.
+struct XcdBroker {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool busy[2] = {false, false};
+    int waiting_full = 0;
+    // returns the half taken (0 / 1), or -1 = both
+    int acquire(bool half) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!half) {
+            ++waiting_full;
+            cv.wait(lk, [&] { return !busy[0] && !busy[1]; });
+            --waiting_full;
+            busy[0] = busy[1] = true;
+            return -1;
+        }
+        cv.wait(lk, [&] { return waiting_full == 0 && (!busy[0] || !busy[1]); });      // a waiting whole-device job goes first
+        const int h = busy[0] ? 1 : 0;
+        busy[h] = true;
+        return h;
+    }
+    void release(int h) {
+        { std::lock_guard<std::mutex> lk(mu); if (h < 0) busy[0] = busy[1] = false; else busy[h] = false; }
+        cv.notify_all();
+    }
+};
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #define TRY(call)                                                                                  \
@@ -55,7 +88,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
         if ((call) != C3D_OK) { job.summary = std::string(#call) + ": " + c3d_last_error(); return false; } \
     } while (0)
 
-bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
+bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, XcdBroker& gpu) {
     const double t0 = now_s();
     const std::string dir = o.out + "/" + job.chrom;
     mkdir(dir.c_str(), 0755);
@@ -85,16 +118,35 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     c3d_fire_params fire;
     c3d_default_fire(&fire);
     TRY(c3d_set_schedule(ctx, stages.data(), (int)stages.size(), &fire, (float)o.gtol, 250));
-    TRY(c3d_init_replicas(ctx, o.models, o.seed, 0));
+    // a chromosome for which a four-XCD geometry exists anneals on half of the device (chosen when its turn comes)
+    bool half = false;
+    if (g_pair && n <= 270) {      // (a four-XCD geometry exists up to 288 beads; above ~270 it costs more than pairing returns: profiles/r05_config4_paired_anneals.txt)
+        TRY(c3d_set_option(ctx, "cluster_xcd_base", 0));
+        TRY(c3d_set_option(ctx, "cluster_xcd_count", 4));
+        TRY(c3d_init_replicas(ctx, o.models, o.seed, 0));
+        double ok = 0;
+        c3d_get_stat(ctx, "cluster_ok", &ok);
+        half = ok != 0;
+    }
+    if (!half) {
+        TRY(c3d_set_option(ctx, "cluster_xcd_base", 0));
+        TRY(c3d_set_option(ctx, "cluster_xcd_count", 8));
+        TRY(c3d_init_replicas(ctx, o.models, o.seed, 0));
+    }
     const double t_front = now_s();
     double t_anneal0 = t_front;
     {   // one anneal at a time per GPU: the multi-step kernel wants every CU; the host phases of the other lanes run meanwhile.
         // Their short device phases (K1: two kernels of ~20 us, coordinate copies) are NOT serialised: a cluster launch whose
         // workgroups find a CU busy with one of them becomes resident as soon as it drains, microseconds later, far inside
         // the 0.3 s after which a launch gives up (c3d_cluster.hip); the fallback counter stays 0 in profiles/r02_config4_*.
-        std::lock_guard<std::mutex> lk(gpu);
+        struct Hold {                               // released on every exit path (TRY returns early)
+            XcdBroker& b; int h;
+            ~Hold() { b.release(h); }
+        } hold{gpu, gpu.acquire(half)};
+        if (half) TRY(c3d_set_option(ctx, "cluster_xcd_base", 4 * hold.h));
         t_anneal0 = now_s();                        // (the wait for the GPU, when another lane anneals, is not this job's anneal)
         TRY(c3d_run(ctx));
+        job.half = half ? hold.h : -1;
     }
     const double t_run = now_s();
     double ms = 0;
@@ -165,9 +217,9 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, std::mutex& gpu) {
     char buf[512];
     const double t_end = now_s();
     snprintf(buf, sizeof buf, "%-14s N=%4d R=%6d  %2d models  best: replica %2d  E_noe %12.1f  Spearman(IF,1/d) %.4f  anneal %6.1f ms (%ld steps)  "
-                              "end-to-end %.2f s  GPU %d  [phases: parse+K1 %.3f, front-half files+start structures %.3f, anneal %.3f, read-back+rank+Spearman %.3f, "
+                              "end-to-end %.2f s  GPU %d%s  [phases: parse+K1 %.3f, front-half files+start structures %.3f, anneal %.3f, read-back+rank+Spearman %.3f, "
                               "PDB+assessment+shaping %.3f s]",
-             job.chrom.c_str(), n, R, M, rank[0] + 1, en[3 * rank[0]], -rho[rank[0]], ms, steps, t_end - t0, job.device, t_k1 - t0, t_front - t_k1,
+             job.chrom.c_str(), n, R, M, rank[0] + 1, en[3 * rank[0]], -rho[rank[0]], ms, steps, t_end - t0, job.device, job.half < 0 ? "" : (job.half ? " XCDs 4-7" : " XCDs 0-3"), t_k1 - t0, t_front - t_k1,
              t_run - t_anneal0, t_score - t_run, t_end - t_score);
     job.summary = buf;
     return true;
@@ -216,8 +268,9 @@ int main(int argc, char** argv) {
         };
         if (s == "--out" || s == "-o") o.out = next("--out");
         else if (s == "--devices") devices = atoi(next("--devices"));
+        else if (s == "--pair") g_pair = atoi(next("--pair")) != 0;
         else if (s == "--map-devices-to") map_to = atoi(next("--map-devices-to"));
-        else if (s == "--lanes") lanes = std::max(1, std::min(4, atoi(next("--lanes"))));
+        else if (s == "--lanes") lanes = std::max(1, std::min(8, atoi(next("--lanes"))));
         else if (s == "-m") o.models = atoi(next("-m"));
         else if (s == "-k") o.K = atof(next("-k"));
         else if (s == "-a") o.alpha = atof(next("-a"));
@@ -226,7 +279,7 @@ int main(int argc, char** argv) {
         else if (s == "--gtol") o.gtol = atof(next("--gtol"));
         else if (s == "--pattern") pattern = next("--pattern");
         else if (s == "--violations") o.violations = true;
-        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text] [--violations] [--map-devices-to P (rehearsal)]\n"); return 0; }
+        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text] [--violations] [--pair 1] [--map-devices-to P (rehearsal)]\n"); return 0; }
         else inputs.push_back(s);
     }
     if (o.out.empty() || inputs.empty() || o.models < 1) { fprintf(stderr, "c3d_batch: need input matrices and --out <root> (see --help)\n"); return 2; }
@@ -256,7 +309,7 @@ int main(int argc, char** argv) {
     // per GPU: `lanes` host threads, each with its own context, take that GPU's jobs in LPT order; while one lane anneals
     // (the GPU phase, serialised per GPU) the other parses, writes the front-half files, scores and writes models
     std::vector<std::thread> workers;
-    std::vector<std::mutex> gpu_mu(devices);
+    std::vector<XcdBroker> gpu_mu(devices);
     std::vector<std::atomic<size_t>> next_job(devices);
     std::vector<std::atomic<int>> lanes_up(devices);
     for (int g = 0; g < devices; ++g) { next_job[g] = 0; lanes_up[g] = 0; }

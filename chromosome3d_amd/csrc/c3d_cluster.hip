@@ -102,10 +102,14 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     // trip of a slot counter (~2 us of every launch).  Not trusted blindly: every workgroup ORs the offset IT sees into one
     // word, and the workgroup that completes the launch refuses the completion mark unless exactly one offset was seen
     // (timeout[2] tells the host why; it re-runs the range step by step and switches this context to the counters).
+    // `static_place` also carries the launch's XCD set (bits 8-15: first XCD, bits 16-23: how many; the preloaded argument dwords are
+    // all taken): replica r lives on XCD first + r % count, and a workgroup on any other XCD has no work.  Two contexts with disjoint
+    // sets anneal side by side (config 4 pairs its small chromosomes: c3d_batch); the default 0 / 8 is the whole device.
     const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0x7);     // HW_REG_XCC_ID
+    const int sp_mode = static_place & 0xff, xcd0 = (static_place >> 8) & 0xff, nxcd = (static_place >> 16) & 0xff;
     int slot;
-    if (static_place) {
-        const unsigned off = ((unsigned)xcc - blockIdx.x + (static_place == 2 && blockIdx.x == 0 ? 1u : 0u)) & 7u;      // 2: test hook
+    if (sp_mode) {
+        const unsigned off = ((unsigned)xcc - blockIdx.x + (sp_mode == 2 && blockIdx.x == 0 ? 1u : 0u)) & 7u;      // 2: test hook
         if (tid == 0) atomicOr(&claim[9], 1u << off);
         slot = (int)(blockIdx.x >> 3);
     } else {
@@ -113,7 +117,8 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
         __syncthreads();
         slot = *s_slot;
     }
-    const int lrep = xcc + 8 * (slot / P), part = slot % P;       // replica index inside this launch's group
+    const int lxcd = xcc - xcd0;                                  // this XCD's index inside the launch's set
+    const int lrep = lxcd + nxcd * (slot / P), part = slot % P;   // replica index inside this launch's group
 #ifdef C3D_STAMPS
     const unsigned long long t_placed = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             }
             traw[r][jb] = t;
         }
-    if (lrep >= m.nrep_g) return;                 // this CU has nothing to do
+    if (lxcd < 0 || lxcd >= nxcd || lrep >= m.nrep_g) return;     // this CU has nothing to do
     const int rep = m.rep_base + lrep;
     const bool solo = P == 1;
     if (!is_compute) __builtin_amdgcn_s_setprio(3);
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 // (replica, part) was never claimed (fewer workgroups on an XCD than the plan assumes) or abandoned never
                 // writes it, and the host re-runs the range on the per-step path instead of accepting stale state.
                 if (lane == 0 && atomicAdd(&claim[8], 1u) + 1u == expected) {
-                    const unsigned seen = static_place ? atomicOr(&claim[9], 0u) : 1u;       // XCD offsets the workgroups saw
+                    const unsigned seen = sp_mode ? atomicOr(&claim[9], 0u) : 1u;       // XCD offsets the workgroups saw
                     if ((seen & (seen - 1u)) == 0u) timeout[1] = tag_base | 1u;
                     else timeout[2] = 1u;
                 }
@@ -581,12 +586,13 @@ hipError_t launch_tear16(int num_cus, void* buf, unsigned* stop, unsigned long l
 // H0's later scalars; measured on 13 problems, N = 76 .. 455 (profiles/r03_late_tiles_ab.txt).  Shipped potential only: every
 // (geometry, LATE) pair is one more kernel to compile.
 
-bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, int forced_late, ClusterPlan* plan) {
+bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, int forced_late, int xcd_count, ClusterPlan* plan) {
     // the placement arithmetic (replica r on XCD r % 8, XCC_ID & 7) is written for the 8 XCDs of an unpartitioned MI355X:
     // on a partitioned or CU-masked device the cluster kernel is not used at all
     if (m.npad > 1024 || num_xcc != 8 || num_cus < 8 || num_cus % 8) return false;
     const int cus_per_xcd = num_cus / 8;
-    const int per_xcd = (m.nrep_g + 7) / 8;
+    if (xcd_count < 1 || xcd_count > 8) return false;
+    const int per_xcd = (m.nrep_g + xcd_count - 1) / xcd_count;      // replicas on the fullest XCD of the launch's set
     const int nb = m.npad / 256;
     // {compute waves, rows per wave, helper waves, workgroups per CU}
     static const int geoms[][4] = {{8, 1, 4, 1}, {8, 2, 4, 1}, {12, 2, 4, 1}, {8, 4, 4, 1}, {10, 4, 4, 1}, {12, 4, 4, 1}, {8, 3, 4, 1},
@@ -635,6 +641,7 @@ bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, 
             plan->grid = num_cus * wpc; plan->threads = threads; plan->units = 2 * rw; plan->device = 0; plan->lds = lds;
             plan->expected = (unsigned)(m.nrep_g * P);
             plan->late_tiles = late;
+            plan->xcd_count = xcd_count;
         }
     }
     return found;
@@ -658,12 +665,13 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
         if (e != hipSuccess) return e;
         attr_set[dev].store(true, std::memory_order_release);
     }
+    const int sp = (pl.static_place & 0xff) | ((pl.xcd_base & 0xff) << 8) | ((pl.xcd_count & 0xff) << 16);      // decoded at the kernel's top
     if (pl.t0 && pl.t1)
         hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, tgt, claim, runs,
-                              pl.parts, pl.cw, pl.helpers, pl.static_place, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);
+                              pl.parts, pl.cw, pl.helpers, sp, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);
     else
         hipLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, tgt, claim, runs, pl.parts, pl.cw, pl.helpers,
-                           pl.static_place, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);
+                           sp, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);
     return hipGetLastError();
 }
 template <int POT>

@@ -122,12 +122,14 @@ AnnealIO anneal_io(const DevBuffers& b, int parity);
 struct ClusterPlan {
     int rpw, cw, helpers, wgs_per_cu, parts, per_xcd, grid, threads, units, device;
     int static_place = 1;                         // slot = blockIdx / 8, checked against the XCC id (0: per-XCD atomic counters)
+    int xcd_base = 0, xcd_count = 8;              // the launch lives on XCDs xcd_base .. xcd_base + xcd_count - 1 (replica r on XCD xcd_base + r % xcd_count): two
+                                                  // contexts with disjoint sets anneal side by side (c3d_set_option "cluster_xcd_count" / "cluster_xcd_base")
     int late_tiles = 0;                           // tile sums fetched by H0 after the step has started instead of gating it (c3d_cluster.hip)
     unsigned expected = 0;                        // workgroups that must report completion: replicas x parts (the host may raise it: test hook)
     size_t lds;
     hipEvent_t t0 = nullptr, t1 = nullptr;        // when set: the launch stamps them with the kernel's own start and end
 };
-bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, int forced_late, ClusterPlan* plan);
+bool cluster_plan(const DevModel& m, int num_cus, int num_xcc, int forced_geom, int forced_late, int xcd_count, ClusterPlan* plan);
 size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl);
 hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout,

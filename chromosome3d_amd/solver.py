@@ -46,6 +46,7 @@ class Solver:
         self._L = _l.load()
         self._h = C.c_void_p()
         _l.check(self._L.c3d_create(device, C.byref(self._h)))
+        self.device = device
         self.n = 0
         self.nrep = 0
 

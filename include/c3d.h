@@ -127,6 +127,11 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *   cluster_static_placement  1 (default): a cluster launch numbers the workgroups of an XCD as blockIdx / 8 and every workgroup
  *                   checks its XCC id against blockIdx % 8; a mismatch abandons the launch and switches the context to 0 =
  *                   per-XCD atomic slot counters (2: test hook, the next launch's workgroup 0 reports a mismatch)
+ *   cluster_xcd_count  8 (default) .. 1: the multi-step launches of this context live on that many XCDs (replica r on XCD cluster_xcd_base +
+ *                   r % count; the planner fits the replicas of the fullest of THEM into its 32 CUs), workgroups elsewhere exit at once; before
+ *                   c3d_init_replicas.  cluster_xcd_base (default 0) = the first of them, may change between launches.  Two contexts with
+ *                   disjoint XCD sets anneal side by side without sharing a CU (c3d_batch pairs config 4's small chromosomes this way); the
+ *                   same bits whatever the set (a replica's trajectory does not depend on where it runs)
  *   cluster_num_xcc, cluster_inject_incomplete, resident_inject_timeout   test hooks of the cluster kernel's safety net
  *                   (a device that does not expose 8 XCDs gets no cluster plan; a launch that ends without its completion
  *                   mark or with a time-out is re-run on the per-step path)
@@ -143,6 +148,10 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *                   a workgroup and four a wave (two packed row pairs; needs pair_targets 1) instead of 8 and two: a wave's fixed work per
  *                   step is shared by twice the pair terms (N = 2500 x 8: 29.8 -> 26.2 us per step).  Another order of a row's sum: equal
  *                   within rounding, not bitwise (measurement knob)
+ *   prefetch_ranks  1 (default) / 0: c3d_set_if_matrix starts the IF side of the Spearman coefficient (average ranks of the matrix's ordered
+ *                   pairs |i-j| >= 3, spearman_IF_pdb.pl:30-44: 5 ms of host time at N = 455) on a helper thread over a copy of the matrix;
+ *                   c3d_score_replicas takes it when its IF argument holds the same numbers, else computes it as before.  Same result
+ *                   either way (measurement knob; stat "rank_prefetch_hits")
  *   start           0 (default) random coil, 1 extended strand (chromosome3D.pl:2413-2416)
  *   use_graph       != 0: per-step path replays hipGraphs (default 1)
  *   replica_groups  1..4 stream groups of the per-step path (default 2);  graph_chunk, rows_per_wave,
@@ -191,7 +200,7 @@ int c3d_last_timing(const c3d_ctx* ctx, double* ms_total, long* steps, long* lau
  * captured + instantiated), "graph_launches", "graphs_cached", "step_launches" (k_step dispatches), "resident_launches",
  * "cluster_launches", "resident_fallbacks" (multi-step launches abandoned for the per-step path), "cluster_incomplete"
  * (those of them that ended without every (replica, part) workgroup reporting), "cluster_static_placement",
- * "cluster_placement_mismatches", "spin_completions" (multi-step launches whose end was seen on the completion mark), "num_xcc", "last_path"
+ * "cluster_placement_mismatches", "cluster_xcd_count", "cluster_xcd_base", "cluster_ok" (1: a multi-step geometry exists for the replicas as initialised), "spin_completions" (multi-step launches whose end was seen on the completion mark), "num_xcc", "last_path"
  * (0 per-step, 2 k_cluster), "cluster_parts", "cluster_rows_per_wave", "cluster_late_tiles", "last_host_launch_us", "last_host_sync_us" (host time inside the launch / synchronise call of the last c3d_run_steps, cluster launches), "cluster_compute_waves", "replica_groups",
  * "k1_recomputed" (elements of the last c3d_set_if_matrix that sat within 1e-10 of a "%.1f" rounding tie and were redone
  * on the host in the reference's operation order), "k1_patched" (how many of those changed, since c3d_create),

@@ -243,17 +243,21 @@ def test_batch_executor_per_device_lists_and_threads_rehearsed_on_one_gpu(built,
         write_if_text(load_if(c), pth)
         mats.append(str(pth))
     runs = {}
-    for tag, extra in (("one", ["--devices", "1", "--lanes", "1"]), ("four", ["--devices", "4", "--lanes", "2", "--map-devices-to", "0"])):
+    for tag, extra in (("one", ["--devices", "1", "--lanes", "1", "--pair", "0"]), ("four", ["--devices", "4", "--lanes", "2", "--map-devices-to", "0"]),
+                       ("paired", ["--devices", "1", "--lanes", "3"])):
         od = tmp_path / tag
         p = subprocess.run([exe] + mats + ["--out", str(od), "-m", "6"] + extra, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout + p.stderr
         assert "6 matrices x 6 models" in p.stdout and "0 failed" in p.stdout
         runs[tag] = (od, p.stdout)
     assert "on 4 GPU(s), 2 lane(s) each" in runs["four"][1]
-    assert sorted(set(re.findall(r"GPU (\d)  \[phases", runs["four"][1]))) == ["0", "1", "2", "3"]      # every logical device took jobs
+    assert sorted(set(re.findall(r"GPU (\d)(?: XCDs \d-\d)?  \[phases", runs["four"][1]))) == ["0", "1", "2", "3"]      # every logical device took jobs
     for chrom in ("chr21_1mb", "chr22_1mb", "chr20_1mb", "chr13_1mb", "chr19_500kb", "chr21_500kb"):
         cid = chrom + "_matrix"
         for k in range(1, 6):
             assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["four"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
+            assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["paired"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
+    # --pair 1 (default), three lanes: the small chromosomes annealed on halves of the device, --pair 0: nobody did
+    assert " XCDs " in runs["paired"][1] and " XCDs " not in runs["one"][1]
     bad = subprocess.run([exe] + mats[:1] + ["--out", str(tmp_path / "x"), "--map-devices-to", "7"], capture_output=True, text=True)
     assert bad.returncode == 2 and "--map-devices-to 7" in bad.stderr

@@ -908,3 +908,28 @@ def test_model_struct_with_a_zero_last_member_means_the_default(solver):
     with pytest.raises(lib.C3DError):
         solver.set_model(m)
     solver.set_model(default_model())
+
+
+def test_if_ranks_prefetched_beside_the_anneal_are_the_ranks_computed_in_place(solver):
+    """c3d_set_if_matrix starts the IF side of the Spearman coefficient on a helper thread (option prefetch_ranks); c3d_score_replicas
+    takes it when its IF argument holds the same numbers, computes it itself for any other matrix: same coefficients bit for bit."""
+    from chromosome3d_amd import default_model, pipeline
+    IF = load_if("chr13_1mb")
+    out = {}
+    for pre in (1, 0):
+        solver.set_option("prefetch_ranks", pre)
+        solver.set_model(default_model())
+        pipeline.IF2dist_new(solver, IF)
+        solver.init_replicas(6, 82364, 0)
+        h0 = solver.stat("rank_prefetch_hits")
+        out[pre] = solver.score(IF)[2].copy()
+        assert solver.stat("rank_prefetch_hits") - h0 == pre
+        other = IF.copy()
+        other[3, 40] *= 1.5                     # not the matrix the context holds: ranked in place
+        other[40, 3] = other[3, 40]
+        rho_other = solver.score(other)[2]
+        assert solver.stat("rank_prefetch_hits") - h0 == pre and not np.array_equal(rho_other, out[pre])
+        assert np.allclose(rho_other, pipeline.spearman_IF_models(other, solver.coords()), rtol=0, atol=1e-12)
+    solver.set_option("prefetch_ranks", 1)
+    assert np.array_equal(out[0], out[1])
+    assert np.allclose(out[1], pipeline.spearman_IF_models(IF, solver.coords()), rtol=0, atol=1e-12)

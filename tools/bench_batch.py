@@ -31,11 +31,12 @@ with tempfile.TemporaryDirectory() as td:
             for row in m:
                 out.write(" ".join(repr(float(v)) for v in row) + " \r\n")
     print(f"wrote {len(os.listdir(ind))} matrices in {time.perf_counter() - t0:.1f} s")
-    for lanes in (1, 2, 3, 4, 2):
-        out = os.path.join(td, f"out{lanes}")
+    for lanes, pair in ((1, 0), (3, 0), (3, 1), (4, 0), (4, 1), (6, 0), (6, 1), (8, 0), (8, 1), (3, 0), (3, 1), (6, 0), (6, 1), (8, 1)):
+        out = os.path.join(td, f"out{lanes}_{pair}")
         t0 = time.perf_counter()
-        p = subprocess.run([os.path.join(ROOT, "chromosome3d_amd", "_lib", "c3d_batch"), ind, "--out", out, "--lanes", str(lanes)],
+        p = subprocess.run([os.path.join(ROOT, "chromosome3d_amd", "_lib", "c3d_batch"), ind, "--out", out, "--lanes", str(lanes), "--pair", str(pair)],
                            capture_output=True, text=True)
         wall = time.perf_counter() - t0
         last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-300:]
-        print(f"lanes {lanes}: process wall {wall:.2f} s (incl. device init); {last}")
+        halves = sum(" XCDs " in l for l in p.stdout.splitlines())
+        print(f"lanes {lanes} pair {pair}: process wall {wall:.2f} s (incl. device init); {halves} anneals on half a device; {last}")
