@@ -121,3 +121,46 @@ def test_philox_known_answer():
     assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_fire_and_lbfgs_reach_the_same_minimum():
+    """The final stage of the reference is `minimize lbfgs nstep=15000 drop=10` x 10 (deck chromosome3D.pl:1790-1803); here it is FIRE
+    (one force evaluation per step, own-row data only).  A documented deviation in ALGORITHM, not in RESULT: from the same
+    post-cooling state, FIRE (the restatement's, as the GPU runs it) and L-BFGS (scipy's L-BFGS-B, 10 correction pairs, on the
+    restatement's energy and its analytic gradient — checked against a central difference first) end in the same minimum: total energy to
+    1e-7 relative, every pair distance to 0.02 A, the same truncated NOE energy rank key, the same Spearman to 1e-4."""
+    from scipy.optimize import minimize
+    from chromosome3d_amd import default_fire, default_model, default_schedule, pipeline
+    from tests.util import load_if, oracle_fire_from, oracle_model_from
+    IF = load_if("chr21_1mb")
+    n = IF.shape[0]
+    d10 = O.if_to_dist10(IF)
+    om, of = oracle_model_from(default_model(), n), oracle_fire_from(default_fire())
+    rows = [(s.kind, s.nsteps, s.dt, s.w_all, s.w_vdw, s.repel_s, s.t_bath) for s in default_schedule(3000)]
+    w_all, w_vdw, rs = rows[-1][3], rows[-1][4], rows[-1][5]
+
+    def fg(u):
+        F, e = O.energy_force(om, d10, u.reshape(n, 3), w_all, w_vdw, rs)
+        return w_all * (e[0] + e[1]) + w_vdw * e[2], -F.ravel()
+    for r in range(3):
+        x0, _, _ = O.run_schedule(om, d10, O.make_stages(rows[:-1]), of, 82364, r)
+        u = x0.ravel().copy()
+        g = fg(u)[1]
+        for k in (5, 17, 3 * n - 2):                                    # the objective L-BFGS sees IS the energy whose force FIRE follows
+            h = 1e-5
+            up, um = u.copy(), u.copy()
+            up[k] += h
+            um[k] -= h
+            assert abs((fg(up)[0] - fg(um)[0]) / (2 * h) - g[k]) <= 1e-5 * max(1.0, abs(g[k]))
+        xf, _, evf = O.run_schedule(om, d10, O.make_stages(rows[-1:]), of, 82364, r, x0=x0, gtol=1e-2, check_every=250)
+        res = minimize(fg, x0.ravel(), jac=True, method="L-BFGS-B", options=dict(maxiter=15000, maxfun=150000, ftol=1e-15, gtol=1e-6, maxcor=10))
+        xl = res.x.reshape(n, 3)
+        ff, fl = fg(xf.ravel())[0], res.fun
+        assert evf < 3000 and res.nit < 15000
+        assert abs(ff - fl) <= 1e-7 * abs(fl), (ff, fl)
+        i, j = np.triu_indices(n, 1)
+        assert np.abs(np.linalg.norm(xf[i] - xf[j], axis=1) - np.linalg.norm(xl[i] - xl[j], axis=1)).max() < 0.02
+        ef = O.energy_force(om, d10, xf, w_all, w_vdw, rs)[1][0]
+        el = O.energy_force(om, d10, xl, w_all, w_vdw, rs)[1][0]
+        assert abs(ef - el) < 1.0                                        # the ranking key is int(E_noe): chromosome3D.pl:796-802
+        assert abs(pipeline.spearman_IF_pdb(IF, xf.astype(np.float32)) - pipeline.spearman_IF_pdb(IF, xl.astype(np.float32))) < 1e-4
