@@ -807,6 +807,49 @@ def test_random_problems_two_contexts_at_once(built):
         assert it >= 30 and any("k_cluster" in name for name in kernels), (it, sorted(kernels))
 
 
+def test_random_problems_two_contexts_on_disjoint_xcd_halves(built):
+    """What config 4's paired anneals rest on (round 5): context A's multi-step launches live on XCDs 0-3, context B's on XCDs 4-7 (options
+    cluster_xcd_count / cluster_xcd_base), both fuzzing at once from two host threads.  Disjoint XCD sets never compete for a CU: the per-step
+    path's bits in both contexts — and, unlike the whole-device pair above, NO abandoned launch in either (only the other context's per-step
+    reference runs and K1 kernels pass through, and those drain in microseconds)."""
+    import sys as _sys
+    import threading
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from chromosome3d_amd import Solver
+    from fuzz_cluster import fuzz
+    out = [None, None]
+    msgs = [[], []]
+
+    def work(k):
+        s = Solver(0)
+        try:
+            out[k] = fuzz(s, seed=991 + k, seconds=8.0, out=msgs[k].append, fallbacks_are_bad=True, xcd_fixed=(4, 4 * k), nmax=288, repmax=20)
+        finally:
+            s.close()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert out[k] is not None, msgs[k]
+        it, bad, kernels = out[k]
+        assert bad == 0, msgs[k]
+        assert it >= 30 and any("k_cluster" in name for name in kernels), (it, sorted(kernels))
+
+
+def test_random_problems_on_random_xcd_sets(solver):
+    """Eight seconds of the fuzz with the multi-step side of every problem on a random XCD set (1..8 XCDs, anywhere they fit, the set moved
+    between launches): the per-step path's bits, no abandoned launch."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_cluster import fuzz
+    msgs = []
+    it, bad, kernels = fuzz(solver, seed=5150, seconds=8.0, out=msgs.append, xcd_sets=True)
+    assert bad == 0, msgs
+    assert it >= 100 and sum("k_cluster" in k for k in kernels) >= 8, (it, sorted(kernels))
+
+
 def test_random_problems_cluster_kernel_equals_per_step_kernel(solver):
     """Eight seconds of tools/fuzz_cluster.py (random sizes, replica counts, chunkings, either hand-off form): same bits, no abandoned
     launch.  The long run is in tools/: 16 463 problems, 36 instantiations of k_cluster, 0 differences."""
