@@ -12,12 +12,16 @@ energy CNS minimised, so under a good model it stays put when minimised again â€
 separately below.  No annealing result enters the fit any more (round 3 fitted the annealed best-energy Spearman to the bundled value).
 
 Which of our 20 replicas to compare: the bundled model of a chromosome is ONE of the reference's 20, and NOT its energy-best â€” the file
-names carry ranks 1..10 (chr22_1mb_rank08, chr4_1mb_rank10, ...); spearman_IF_pdb.pl:73-76 prints the models sorted by their Spearman,
-and that is by all appearance how it was picked.  Both readings are asserted:
-  * best-ENERGY replica (the literal north star): 43 of 45 within +-0.01 (8 seeds: 43 seven times, 42 once: profiles/r04_seed_robustness_all45.md);
-    the two outside are named below, strict xfail â€” on both our energy prefers another fold than the bundled one (by 0.75 % of E_noe on chr7_1mb, 5 % on chr22_1mb) while
-    the bundled fold is present among our 20 replicas (chr22_1mb: the bundled model is the reference's rank 8; chr7_1mb: rank 2);
-  * best-SPEARMAN replica (like for like with how the bundled file was chosen): 45 of 45 within +-0.01, bias +0.0010."""
+names carry ranks 1..10 (chr22_1mb_rank08, chr4_1mb_rank10, ...), never 11..20: it was picked among the ten lowest-energy models, by all
+appearance for its Spearman (spearman_IF_pdb.pl:73-76 prints the models sorted by it; order statistics: test below).  THE GATE is the
+literal north star:
+  * best-ENERGY replica: 43 of 45 within +-0.01 (8 seeds: 43 seven times, 42 once: profiles/r04_seed_robustness_all45.md); the two outside
+    are named below, STRICT xfails with hard bounds â€” on both our energy prefers another fold than the bundled one (by 0.75 % of E_noe on
+    chr7_1mb, 5 % on chr22_1mb).  Round 5 asked the reference's own energy ranks (the rankNN of the file names): relaxed under our energy the
+    bundled chr22_1mb (file rank 8) is 19th of our 20, chr7_1mb (rank 2) 11th â€” the model gap is real, not an artefact of which replica is
+    compared; chr22_1mb's -0.034 (round 3: -0.019) is a known loss of round 4's lower side, recorded in DESIGN.md section 2 item 4.
+  * information only (selected on the metric under test, hence no gate): best Spearman of our 20 â€” 45 of 45 â€” and of our ten lowest-energy
+    replicas â€” 44 of 45, bias -0.0003."""
 import glob
 import os
 import re
