@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
     // on this cold load before the target and velocity loads below are even on their way
     const float4* pp = reinterpret_cast<const float4*>(pin) + (size_t)rep * m.ntiles;
     float4 q0 = make_float4(0, 0, 0, 0);
-    if (needs_partials && lane < m.ntiles) q0 = pp[lane];
+    if (needs_partials && lane < m.ntiles && (!WIDE || wave == 0)) q0 = pp[lane];      // (wide form: wave 0 alone forms the replica sums, below)
     float4 tv[RPW];
     if (p.kind != 4) {
         if (pair_targets_in_use<POT, GEN, RPW, NC>(m)) pair_targets_prefetch(m, row0, lane, 0, tv);
@@ -126,8 +126,13 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
     FireState st;
     st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0;
     if (p.kind == 2) st = sin[rep];
+    // WIDE (large N: hundreds of tile sums): ONE wave of the workgroup forms the replica sums and the step's scalars and hands them to the
+    // others through LDS across the barrier that waits for the coordinates anyway — the same values, the same bits (every wave used to
+    // derive them for itself: ~90 of a wave's ~2200 VALU instructions per step at N = 2500, three quarters of them redundant)
+    float* const scb = rowq + 4 * TR;           // [12]: StepScalars (6) + FireState (4)
+    const bool sums_here = !WIDE || wave == 0;
     float4 psum = make_float4(0, 0, 0, 0);
-    if (needs_partials) {   // one float4 per tile; ntiles <= 64 for N <= 512
+    if (needs_partials && sums_here) {   // one float4 per tile; ntiles <= 64 for N <= 512
         psum.x += q0.x; psum.y += q0.y; psum.z += q0.z; psum.w += q0.w;
         for (int t = lane + 64; t < m.ntiles; t += 64) {
             const float4 q = pp[t];
@@ -136,12 +141,28 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
     }
     C3D_STAMP(1);
 
-    // ---- 2. scalars per wave (no barrier; every wave derives the same values) -----------------
-    if (needs_partials) psum = wave_sum4(psum);
-    const StepScalars sc = step_scalars(m, p, fp, psum, st);
-    if ((p.kind == 2 || p.kind == 3) && tile == 0 && tid == 0) sout[rep] = st;
+    // ---- 2. scalars per wave (no barrier of their own; every wave ends with the same values) -----------------
+    StepScalars sc;
+    sc.lam = 1.0f; sc.cmx = sc.cmy = sc.cmz = 0.0f; sc.keep = 0.0f; sc.mix = 0.0f;
+    if (sums_here) {
+        if (needs_partials) psum = wave_sum4(psum);
+        sc = step_scalars(m, p, fp, psum, st);
+        if ((p.kind == 2 || p.kind == 3) && tile == 0 && tid == 0) sout[rep] = st;
+        if constexpr (WIDE) {
+            if (lane == 0) {
+                scb[0] = sc.lam; scb[1] = sc.cmx; scb[2] = sc.cmy; scb[3] = sc.cmz; scb[4] = sc.keep; scb[5] = sc.mix;
+                scb[6] = st.dt; scb[7] = st.alpha; reinterpret_cast<int*>(scb)[8] = st.npos; reinterpret_cast<int*>(scb)[9] = st.pad;
+            }
+        }
+    }
     C3D_STAMP(2);
     __syncthreads();
+    if constexpr (WIDE) {
+        if (!sums_here) {
+            sc.lam = scb[0]; sc.cmx = scb[1]; sc.cmy = scb[2]; sc.cmz = scb[3]; sc.keep = scb[4]; sc.mix = scb[5];
+            st.dt = scb[6]; st.alpha = scb[7]; st.npos = reinterpret_cast<const int*>(scb)[8]; st.pad = reinterpret_cast<const int*>(scb)[9];
+        }
+    }
     C3D_STAMP(3);
 
     // ---- 3. K2: pair forces for this wave's rows ---------------------------------------------
@@ -190,7 +211,7 @@ hipError_t launch_pair_targets(const DevModel& m, const float* tgt, float* tgs2,
     return hipGetLastError();
 }
 
-static size_t step_lds_bytes(const DevModel& m, int tile_rows = kTileRows) { return sizeof(float) * ((size_t)3 * m.npad + 4 * tile_rows); }   // xyz + rowq
+static size_t step_lds_bytes(const DevModel& m, int tile_rows = kTileRows) { return sizeof(float) * ((size_t)3 * m.npad + 4 * tile_rows + 12); }   // xyz + rowq + the wide form's scalar hand-over
 
 template <int POT, bool GEN, int RPW>
 static hipError_t launch_step_r(const DevModel& m0, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par, bool wide,
