@@ -62,6 +62,9 @@ inline dim3 grid_blocks(const DevModel& m) { return dim3(8, m.nrep_g, (m.ntiles 
 // TR = rows of a workgroup: kTileRows, or (WIDE) two 8-row tiles with four rows per wave in the packed form — problems beyond the multi-step
 // kernel's reach (n > 1024), where a wave's fixed work per step (sums, scalars, chain terms, row update: ~500 instructions) was a third of
 // its instructions at two rows per wave; the tile sums keep their 8-row tree and their place in P
+#ifndef C3D_SHARE_SCALARS
+#define C3D_SHARE_SCALARS 1      // 0: measurement builds in which every wave derives the step's scalars for itself (rounds 1-4)
+#endif
 template <int POT, bool GEN, int RPW, bool NC, int TR = kTileRows, bool WIDE = false>
 __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : 1))) void k_step(
     const float* __restrict__ pin, const float* __restrict__ xin, const float* __restrict__ tgt,
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
     // on this cold load before the target and velocity loads below are even on their way
     const float4* pp = reinterpret_cast<const float4*>(pin) + (size_t)rep * m.ntiles;
     float4 q0 = make_float4(0, 0, 0, 0);
-    if (needs_partials && lane < m.ntiles && (!WIDE || wave == 0)) q0 = pp[lane];      // (wide form: wave 0 alone forms the replica sums, below)
+    if (needs_partials && lane < m.ntiles && (!WIDE || !C3D_SHARE_SCALARS || wave == 0)) q0 = pp[lane];      // (wave 0 alone forms the replica sums, below)
     float4 tv[RPW];
     if (p.kind != 4) {
         if (pair_targets_in_use<POT, GEN, RPW, NC>(m)) pair_targets_prefetch(m, row0, lane, 0, tv);
@@ -129,8 +132,10 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
     // WIDE (large N: hundreds of tile sums): ONE wave of the workgroup forms the replica sums and the step's scalars and hands them to the
     // others through LDS across the barrier that waits for the coordinates anyway — the same values, the same bits (every wave used to
     // derive them for itself: ~90 of a wave's ~2200 VALU instructions per step at N = 2500, three quarters of them redundant)
+    constexpr bool SHARE = WIDE && C3D_SHARE_SCALARS;       // (narrow form, N = 455 x 20, same box: 6.92 us per step shared against 6.78 per wave — its
+                                                            //  waves would wait at the barrier for a chain they used to run beside their own loads)
     float* const scb = rowq + 4 * TR;           // [12]: StepScalars (6) + FireState (4)
-    const bool sums_here = !WIDE || wave == 0;
+    const bool sums_here = !SHARE || wave == 0;
     float4 psum = make_float4(0, 0, 0, 0);
     if (needs_partials && sums_here) {   // one float4 per tile; ntiles <= 64 for N <= 512
         psum.x += q0.x; psum.y += q0.y; psum.z += q0.z; psum.w += q0.w;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
         if (needs_partials) psum = wave_sum4(psum);
         sc = step_scalars(m, p, fp, psum, st);
         if ((p.kind == 2 || p.kind == 3) && tile == 0 && tid == 0) sout[rep] = st;
-        if constexpr (WIDE) {
+        if constexpr (SHARE) {
             if (lane == 0) {
                 scb[0] = sc.lam; scb[1] = sc.cmx; scb[2] = sc.cmy; scb[3] = sc.cmz; scb[4] = sc.keep; scb[5] = sc.mix;
                 scb[6] = st.dt; scb[7] = st.alpha; reinterpret_cast<int*>(scb)[8] = st.npos; reinterpret_cast<int*>(scb)[9] = st.pad;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
     }
     C3D_STAMP(2);
     __syncthreads();
-    if constexpr (WIDE) {
+    if constexpr (SHARE) {
         if (!sums_here) {
             sc.lam = scb[0]; sc.cmx = scb[1]; sc.cmy = scb[2]; sc.cmz = scb[3]; sc.keep = scb[4]; sc.mix = scb[5];
             st.dt = scb[6]; st.alpha = scb[7]; st.npos = reinterpret_cast<const int*>(scb)[8]; st.pad = reinterpret_cast<const int*>(scb)[9];
@@ -211,7 +216,7 @@ hipError_t launch_pair_targets(const DevModel& m, const float* tgt, float* tgs2,
     return hipGetLastError();
 }
 
-static size_t step_lds_bytes(const DevModel& m, int tile_rows = kTileRows) { return sizeof(float) * ((size_t)3 * m.npad + 4 * tile_rows + 12); }   // xyz + rowq + the wide form's scalar hand-over
+static size_t step_lds_bytes(const DevModel& m, int tile_rows = kTileRows) { return sizeof(float) * ((size_t)3 * m.npad + 4 * tile_rows + 12); }   // xyz + rowq + the step scalars' hand-over
 
 template <int POT, bool GEN, int RPW>
 static hipError_t launch_step_r(const DevModel& m0, const DevStep& p, const DevFire& fp, const DevBuffers& b, int par, bool wide,
