@@ -401,8 +401,13 @@ __device__ __forceinline__ void pair_term2(const PairK2& k, float2v v2, float2v 
     const float2v rinv = float2v{__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
     float2v q01;                                                                                   // clamp01(1 - r2 / R2)
     asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(q01) : "v"(r2), "v"(k.k0));
+#ifdef C3D_EXP_FOLD_D
+    // measurement build only (valid for mrswitch = 1, where mw2 = 1): what coordinates in units of mrswitch would save — d - t in ONE fma
+    const float2v dl = __builtin_elementwise_fma(r2, rinv, -v2);
+#else
     const float2v d = r2 * rinv;
     const float2v dl = __builtin_elementwise_fma(d, mw2, -v2);
+#endif
     const float2v w = float2v{__builtin_amdgcn_rcpf(fabsf(dl.x)), __builtin_amdgcn_rcpf(fabsf(dl.y))};
     const float2v lo = -((w * w) * w);
     const float2v g = float2v{__builtin_amdgcn_fmed3f(dl.x, lo.x, k.k1.y), __builtin_amdgcn_fmed3f(dl.y, lo.y, k.k1.y)};
@@ -696,8 +701,17 @@ __device__ __forceinline__ void tile_pair_sums_pk(const DevModel& m, const DevSt
 #endif
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int ra = min(row0 + 2 * q, m.n - 1), rb = min(row0 + 2 * q + 1, m.n - 1);
-        xi2[q] = float2v{xs[ra], xs[rb]}; yi2[q] = float2v{ys[ra], ys[rb]}; zi2[q] = float2v{zs[ra], zs[rb]};
+        // the two rows of a pair are neighbours in LDS and the pair starts on an even row (RPW is even here, a workgroup's first row a
+        // multiple of 8): ONE 8-byte read per coordinate instead of two reads and the moves that pair them up.  A row beyond the last bead
+        // reads a padding bead (1e4 A away; the arrays hold 256 NB entries) — its sums are finite and nobody takes them (as before, when
+        // such a row re-read the last bead)
+        const int ra = min(row0 + 2 * q, 256 * NB - 2);
+        if constexpr ((RPW & 1) == 0) {
+            xi2[q] = *reinterpret_cast<const float2v*>(xs + ra); yi2[q] = *reinterpret_cast<const float2v*>(ys + ra); zi2[q] = *reinterpret_cast<const float2v*>(zs + ra);
+        } else {
+            const int rb = min(row0 + 2 * q + 1, 256 * NB - 1);
+            xi2[q] = float2v{xs[ra], xs[rb]}; yi2[q] = float2v{ys[ra], ys[rb]}; zi2[q] = float2v{zs[ra], zs[rb]};
+        }
         fx2[q] = fy2[q] = fz2[q] = float2v{0.0f, 0.0f};
     }
     if constexpr (RPW & 1) { const int row = min(row0 + RPW - 1, m.n - 1); xis = xs[row]; yis = ys[row]; zis = zs[row]; }
