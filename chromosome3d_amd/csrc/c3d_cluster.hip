@@ -413,9 +413,9 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                         const float cx = cbuf[lane], cy = cbuf[64 + lane], cz = cbuf[128 + lane];
                         const bool lo = m.nleft > 0;
                         const float sx = lo ? sx0 + lx : sx0, sy = lo ? sy0 + ly : sy0, sz = lo ? sz0 + lz : sz0;
-                        Fx = pair_sum_scaled<false>(pk, sx) + cx;
-                        Fy = pair_sum_scaled<false>(pk, sy) + cy;
-                        Fz = pair_sum_scaled<false>(pk, sz) + cz;
+                        Fx = row_total<false>(pk, sx, cx);        // one explicit fma, as in reduce_and_chain (c3d_step_core.h)
+                        Fy = row_total<false>(pk, sy, cy);
+                        Fz = row_total<false>(pk, sz, cz);
                     }
                     float vx0 = vcx, vy0 = vcy, vz0 = vcz;
                     if constexpr (K == 3) { vx0 = vy0 = vz0 = 0.0f; }

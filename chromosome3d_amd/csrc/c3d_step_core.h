@@ -210,10 +210,16 @@ __device__ __forceinline__ void pair_term(const DevModel& m, const DevStep& p, c
     fy = fmaf(c, dy, fy);
     fz = fmaf(c, dz, fz);
 }
-// a row's pair force from the reduced sum of its pair terms: the clamp form's common factor comes back here
+// a row's force from the reduced sum of its pair terms and its chain sum: the clamp form's common factor comes back here
+// A row's force = its pair sum times the row factor PLUS its chain sum — as ONE explicit fma (round 5).  It used to be written as a
+// product and a sum, and the library is built with -ffp-contract=fast, under which the BACKEND may fuse a multiplication with a following
+// addition whatever `#pragma clang fp contract(off)` says about the source: every instantiation of every launch form did fuse it, which is
+// why they agreed bit for bit — until a restructuring of the pair term changed the instruction selector's mind for the y and z components
+// of ONE instantiation (k_cluster<4, 2, 2, 3, false>: 1-ulp differences in 40 % of the rows; profiles/r05_units_of_mrswitch_experiment.txt).
+// Written as llvm.fma the fusion is what the source says, in every kernel, under any compiler.
 template <bool GEN>
-__device__ __forceinline__ float pair_sum_scaled(const DevStep& p, float fsum) {
-    if constexpr (GEN) return fsum; else return p.w_rs * fsum;
+__device__ __forceinline__ float row_total(const DevStep& p, float pair_sum, float chain_sum) {
+    if constexpr (GEN) return pair_sum + chain_sum; else return fmaf(p.w_rs, pair_sum, chain_sum);
 }
 
 // per-pair constants of four targets (Angstrom, 0 = none).  Clamp form: (t / rs, 1 / rs or 0); general tails: (t, W or 0)
@@ -334,10 +340,8 @@ __device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevSte
             if (lane == q) { Fx += ax; Fy += ay; Fz += az; }
         }
     }
-    Fx = pair_sum_scaled<GEN>(p, Fx);
-    Fy = pair_sum_scaled<GEN>(p, Fy);
-    Fz = pair_sum_scaled<GEN>(p, Fz);
     const int nb = lane & 3, half = (lane >> 2) & 1;     // lanes 0..3 serve even rows, 4..7 odd rows
+    float Cx = 0.0f, Cy = 0.0f, Cz = 0.0f;               // this lane's row's chain sum (exactly one pass delivers it)
 #pragma unroll
     for (int pass = 0; pass < (RPW + 1) / 2; ++pass) {
         // the row of {row0 + 2 pass, row0 + 2 pass + 1} whose parity is `half`
@@ -348,10 +352,13 @@ __device__ __forceinline__ void reduce_and_chain(const DevModel& m, const DevSte
         // lane r < 4 takes its own quad's sum if that is its row's, else the sum of lanes 4..7 (row_ror:12 = lane + 4)
         const float ox = dpp_mov<0x12C>(cx), oy = dpp_mov<0x12C>(cy), oz = dpp_mov<0x12C>(cz);
         const bool own = lane == rsel, other = lane == (rsel ^ 1);   // in lanes 0..3 rsel is the even-quad row of this pass
-        Fx += own ? cx : (other ? ox : 0.0f);
-        Fy += own ? cy : (other ? oy : 0.0f);
-        Fz += own ? cz : (other ? oz : 0.0f);
+        Cx = own ? cx : (other ? ox : Cx);
+        Cy = own ? cy : (other ? oy : Cy);
+        Cz = own ? cz : (other ? oz : Cz);
     }
+    Fx = row_total<GEN>(p, Fx, Cx);
+    Fy = row_total<GEN>(p, Fy, Cy);
+    Fz = row_total<GEN>(p, Fz, Cz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -592,7 +599,7 @@ __device__ __forceinline__ void tile_forces(const DevModel& m, const DevStep& p,
 
 // clamp form with the per-pair constants resident for a whole launch (cluster kernel, compute waves): tv = pair_b in
 // registers, mw_lds = pair_a in LDS; NB column blocks, fully unrolled.  Returns the butterfly sums of the PAIR terms only,
-// WITHOUT the row factor (pair_sum_scaled): lane l holds the sum for row row0 + (l & 3) (RPW >= 3), row0 + (l & 1) (RPW = 2),
+// WITHOUT the row factor (row_total): lane l holds the sum for row row0 + (l & 3) (RPW >= 3), row0 + (l & 1) (RPW = 2),
 // row0 (RPW = 1); factor and chain terms are added by the finishing wave.
 // NARROW = keep only four pair terms in flight (register budget).
 template <int POT, int RPW, int NB, int WL, int NARROW>
