@@ -289,13 +289,15 @@ __device__ __forceinline__ void chain_term(const DevModel& m, const DevStep& p, 
         const float dx = xs[row] - xs[jn], dy = ys[row] - ys[jn], dz = zs[row] - zs[jn];
         const float r2 = fmaxf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)), 1e-12f);
         const float rinv = __builtin_amdgcn_rsqf(r2);
-        const float d = r2 * rinv;
+        float d = r2 * rinv;
+        asm("" : "+v"(d));                           // a product that "- r0" follows: pinned, see row_total
         const float k2 = sep == 1 ? m.k_bond2 : m.k_ang2;
         const float r0 = sep == 1 ? m.b0 : m.a0;
         const bool on = sep == 1 || (m.k_ang2 > 0.0f && (m.ang_mode == 1 || d < m.a0));
         float c = on ? -p.w_all * k2 * (d - r0) * rinv : 0.0f;
         if (sep < m.rep_sep) c = fmaf(-p.w_rep4, fmaxf(p.rep_r2 - r2, 0.0f), c);
         cx = c * dx; cy = c * dy; cz = c * dz;
+        asm("" : "+v"(cx), "+v"(cy), "+v"(cz));      // products that the quad sum adds up next: pinned, see row_total
     }
 }
 // sum of the four chain terms of a row held by the four lanes of a quad, (c0 + c1) + (c2 + c3), in every lane of it
@@ -789,10 +791,14 @@ __device__ __forceinline__ StepScalars step_scalars(const DevModel& m, const Dev
         // between the arrival of the sums and the pair loop, and the correctly rounded sequences are ~35
         // dependent instructions each
         const float tprev = fmaxf(m.t_fac * psum.x, 1e-2f);
-        const float ratio = p.t_bath * __builtin_amdgcn_rcpf(tprev);
-        if (p.kind == 0) s.lam = __builtin_amdgcn_sqrtf(fmaxf(fmaf(p.dt * m.fbeta, ratio - 1.0f, 1.0f), 0.0f));
-        else s.lam = __builtin_amdgcn_sqrtf(ratio);
+        // (T0 / T - 1 as ONE explicit fma: what every instantiation's backend made of "product, then - 1" under -ffp-contract=fast; see row_total)
+        const float rt = __builtin_amdgcn_rcpf(tprev);
+        if (p.kind == 0) s.lam = __builtin_amdgcn_sqrtf(fmaxf(fmaf(p.dt * m.fbeta, fmaf(p.t_bath, rt, -1.0f), 1.0f), 0.0f));
+        else s.lam = __builtin_amdgcn_sqrtf(p.t_bath * rt);
         s.cmx = psum.y * m.inv_n; s.cmy = psum.z * m.inv_n; s.cmz = psum.w * m.inv_n;
+        // products that a subtraction follows (finish_row: v - v_cm): hidden from the instruction selector, so that "product, then difference"
+        // is what every kernel computes whatever the backend would like to fuse under -ffp-contract=fast (see row_total)
+        asm("" : "+v"(s.cmx), "+v"(s.cmy), "+v"(s.cmz));
     } else if (p.kind == 2 || p.kind == 3) {
         // FIRE (Bitzek et al. 2006) with the power test on the previous step's sums
         if (psum.x > 0.0f) {

@@ -146,8 +146,9 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *                   constants from the target matrix in every step.  Same bits either way (measurement knob)
  *   wide_tiles      1 (default) / 0: beyond the multi-step kernel's reach (n > 1024) the per-step kernel of the shipped potential runs 16 rows
  *                   a workgroup and four a wave (two packed row pairs; needs pair_targets 1) instead of 8 and two: a wave's fixed work per
- *                   step is shared by twice the pair terms (N = 2500 x 8: 29.8 -> 26.2 us per step).  Another order of a row's sum: equal
- *                   within rounding, not bitwise (measurement knob)
+ *                   step is shared by twice the pair terms (N = 2500 x 8: 29.8 -> 26.2 us per step).  Through round 4 equal to the narrow form within rounding
+ *                   only; since round 5 — a row's force is one explicit fma in every form — the same bits in every problem of tools/fuzz_wide.py
+ *                   (measurement knob)
  *   prefetch_ranks  1 (default) / 0: c3d_set_if_matrix starts the IF side of the Spearman coefficient (average ranks of the matrix's ordered
  *                   pairs |i-j| >= 3, spearman_IF_pdb.pl:30-44: 5 ms of host time at N = 455) on a helper thread over a copy of the matrix;
  *                   c3d_score_replicas takes it when its IF argument holds the same numbers, else computes it as before.  Same result
