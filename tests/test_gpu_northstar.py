@@ -76,10 +76,13 @@ def _solve(solver, cid, nrep=20, seed=82364):
     solver.set_schedule(default_schedule(3000), default_fire(), 0.0, 250)
     solver.init_replicas(nrep, seed, 0)
     solver.run()
-    x, e = solver.coords(), solver.energies()[:, 0]
+    x, e3 = solver.coords(), solver.energies()
+    e = e3[:, 0]
     rep = structure_report(IF, x, e, Xr, bundled_rank(ref[0]), pipeline.restraints_from_dist10(d10))
     rep["x_best"] = x[rep["best"]].astype(np.float64)
     rep["file_rank"] = bundled_rank(ref[0])
+    rep["e_total"] = e3.sum(axis=1)               # what the anneal and the minimiser descend on (final stage: all weights 1)
+    rep["e_chain_repel"] = e3[:, 1:].sum(axis=1)
     rep["relaxed"] = relax_reference_model(solver, Xr, e)          # replaces the solver's replicas: last
     return rep
 
@@ -226,6 +229,24 @@ def test_reference_energy_ranks_against_ours(solver):
     assert gap.min() >= -0.05 and gap.max() <= 0.08, (gap.min(), gap.max())   # measured -3.4 % (chr13_1mb) .. +6.0 % (chr11_1mb) of our best E_noe
     for c in EDGE:                                                             # the named outliers: our energy ranks the bundled fold LOW
         assert reps[c]["relaxed"]["rank_in_ours"] > reps[c]["file_rank"] + 5, (c, reps[c]["relaxed"]["rank_in_ours"])
+
+
+def test_bundled_models_by_total_energy_lie_inside_our_field(solver):
+    """The reference ranks by NOE energy alone (chromosome3D.pl:796-802); by THAT figure the relaxed bundled model is below all 20 of
+    ours on about a dozen rows (test_reference_energy_ranks_against_ours).  By the TOTAL energy — E_noe + bond/angle + repel at the final
+    stage's weights, what our anneal and minimiser descend on — it is below all of ours on 2 of 45 (chr13_1mb by 2.5 %: the one real
+    search gap) and takes the median place 8 of 21: the bundled models pay for NOE energy with chain and repel energy
+    (profiles/r05_total_energy_ranks.md; measured 2 / 3 above all / median 8 / mean excess of chain + repel over our medians +3 000)."""
+    rk_noe, rk_tot, excess = [], [], []
+    for cid in CIDS:
+        r = _report(solver, cid)
+        tot = float(r["relaxed"]["e3"].sum())
+        rk_noe.append(r["relaxed"]["rank_in_ours"]); rk_tot.append(int(1 + (r["e_total"] < tot).sum()))
+        excess.append(float(r["relaxed"]["e3"][1:].sum() - np.median(r["e_chain_repel"])))
+    rk_noe, rk_tot, excess = np.array(rk_noe), np.array(rk_tot), np.array(excess)
+    assert (rk_tot == 1).sum() <= 4 < (rk_noe == 1).sum(), (rk_tot, rk_noe)
+    assert (rk_tot == 21).sum() <= 6 and 5 <= np.median(rk_tot) <= 12, rk_tot
+    assert np.median(rk_tot) > np.median(rk_noe) and (excess > 0).sum() >= 27, (np.median(rk_tot), np.median(rk_noe), (excess > 0).sum())
 
 
 def test_order_statistics_of_how_the_bundled_model_was_picked(solver):

@@ -168,8 +168,9 @@ def relax_reference_model(solver, ref_xyz, e_noe_ours, min_steps=3000, gtol=1e-2
     solver.init_replicas(1, 82364, 0)
     solver.set_coords(ref_xyz[None])
     solver.run()
-    e = float(solver.energies()[0, 0])
+    e3 = solver.energies()[0].copy()              # (E_noe, bond + angle, repel), unweighted, at the final stage's weights
+    e = float(e3[0])
     x = solver.coords()[0]
     ours = np.asarray(e_noe_ours).astype(np.int64)
     return dict(e_noe=e, rank_in_ours=int(1 + (ours < int(e)).sum()), moved=pipeline.model_similarity(x, ref_xyz), xyz=x,
-                rel_gap=float((e - ours.min()) / ours.min()))
+                rel_gap=float((e - ours.min()) / ours.min()), e3=e3)
