@@ -8,7 +8,7 @@
 //   assess_dgsa (:106, :769-829)                              c3d_rank, c3d_assess, c3d_write_pdb, c3d_shape_pdb, top 5 renamed
 // Matrices go to GPUs by longest-processing-time-first on N^2 (the restraint count), largest first on every GPU.
 //
-//   c3d_batch <dir with *_matrix.txt | matrix files...> --out <root> [--devices <all>] [--lanes 3] [-m 20] [-k 11] [-a 0.5]
+//   c3d_batch <dir with *_matrix.txt | matrix files...> --out <root> [--devices <all>] [--lanes 3] [--order warm|lpt] [-m 20] [-k 11] [-a 0.5]
 //             [--seed 82364] [--min-steps 3000] [--gtol 1e-2] [--pattern _500kb_]
 //             [--pair 1]             1 (default): two small chromosomes anneal side by side on disjoint halves of a device's XCDs; 0: one at a time
 //             [--map-devices-to P]   rehearsal hook: every logical device 0 .. N-1 of --devices N is physical device P (the per-device
@@ -50,6 +50,9 @@ struct Options {
     bool violations = false;       // --violations: also leave contact_violation.txt (:475-483; 180 MB of text per chromosome at N = 455)
 };
 std::mutex g_print;
+bool g_timeline = false;           // env C3D_BATCH_TIMELINE
+double g_t0 = 0;
+bool g_warm = true;                // --order lpt: a GPU's lanes start on its largest jobs (round 4); warm (round 5): see main
 bool g_pair = true;                // --pair 0: every anneal has the whole device to itself (round 4)
 
 // Who anneals where on one physical device.  The multi-step kernel places replica r on XCD base + r % count (c3d.h, option
@@ -222,6 +225,11 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, XcdBroker& gpu) {
              job.chrom.c_str(), n, R, M, rank[0] + 1, en[3 * rank[0]], -rho[rank[0]], ms, steps, t_end - t0, job.device, job.half < 0 ? "" : (job.half ? " XCDs 4-7" : " XCDs 0-3"), t_k1 - t0, t_front - t_k1,
              t_run - t_anneal0, t_score - t_run, t_end - t_score);
     job.summary = buf;
+    if (g_timeline) {                                 // C3D_BATCH_TIMELINE=1: when each phase of each job ran, seconds since the executor's start
+        std::lock_guard<std::mutex> lk(g_print);
+        fprintf(stderr, "timeline %-12s N=%4d start %.4f parsed+K1 %.4f front %.4f got-GPU %.4f annealed %.4f scored %.4f end %.4f%s\n", job.chrom.c_str(), n,
+                t0 - g_t0, t_k1 - g_t0, t_front - g_t0, t_anneal0 - g_t0, t_run - g_t0, t_score - g_t0, t_end - g_t0, job.half < 0 ? "" : (job.half ? " half 1" : " half 0"));
+    }
     return true;
 }
 
@@ -269,6 +277,7 @@ int main(int argc, char** argv) {
         if (s == "--out" || s == "-o") o.out = next("--out");
         else if (s == "--devices") devices = atoi(next("--devices"));
         else if (s == "--pair") g_pair = atoi(next("--pair")) != 0;
+        else if (s == "--order") g_warm = std::string(next("--order")) != "lpt";
         else if (s == "--map-devices-to") map_to = atoi(next("--map-devices-to"));
         else if (s == "--lanes") lanes = std::max(1, std::min(8, atoi(next("--lanes"))));
         else if (s == "-m") o.models = atoi(next("-m"));
@@ -279,7 +288,7 @@ int main(int argc, char** argv) {
         else if (s == "--gtol") o.gtol = atof(next("--gtol"));
         else if (s == "--pattern") pattern = next("--pattern");
         else if (s == "--violations") o.violations = true;
-        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text] [--violations] [--pair 1] [--map-devices-to P (rehearsal)]\n"); return 0; }
+        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text] [--violations] [--pair 1] [--order warm|lpt] [--map-devices-to P (rehearsal)]\n"); return 0; }
         else inputs.push_back(s);
     }
     if (o.out.empty() || inputs.empty() || o.models < 1) { fprintf(stderr, "c3d_batch: need input matrices and --out <root> (see --help)\n"); return 2; }
@@ -304,7 +313,23 @@ int main(int argc, char** argv) {
         load[g] += jobs[k].cost;
         mine[g].push_back(k);
     }
+    // Order WITHIN a GPU's queue (the assignment to GPUs above stays LPT).  The GPU has nothing to anneal until the first job has been
+    // parsed and its front half written, and a large matrix takes 30-50 ms of that on a cold lane: with "warm" the first lane starts on the
+    // GPU's largest job and the other lanes on its SMALLEST ones (1 ms of parsing), so the device is annealing a few milliseconds after the
+    // contexts exist and the large parses run beside those anneals; the rest follows largest first.  Results do not depend on the order.
+    if (g_warm && lanes > 1)
+        for (int g = 0; g < devices; ++g) {
+            std::vector<size_t>& q = mine[g];
+            const size_t small = std::min((size_t)(lanes - 1), q.size() > 1 ? q.size() - 1 : 0);
+            if (small == 0) continue;
+            std::vector<size_t> head(1, q[0]);
+            for (size_t k = 0; k < small; ++k) head.push_back(q[q.size() - 1 - k]);        // smallest first
+            head.insert(head.end(), q.begin() + 1, q.end() - small);
+            q.swap(head);
+        }
     const double t0 = now_s();
+    g_t0 = t0;
+    g_timeline = getenv("C3D_BATCH_TIMELINE") != nullptr;
     std::atomic<int> failed{0};
     // per GPU: `lanes` host threads, each with its own context, take that GPU's jobs in LPT order; while one lane anneals
     // (the GPU phase, serialised per GPU) the other parses, writes the front-half files, scores and writes models
@@ -324,6 +349,7 @@ int main(int argc, char** argv) {
                 return;
             }
             ++lanes_up[g];
+            if (g_timeline) { std::lock_guard<std::mutex> lk(g_print); fprintf(stderr, "timeline lane of GPU %d has its context at %.4f\n", g, now_s() - g_t0); }
             for (;;) {
                 const size_t at = next_job[g]++;
                 if (at >= mine[g].size()) break;
