@@ -185,6 +185,8 @@ struct c3d_ctx {
         bool valid = false;
         void join() { if (worker.joinable()) worker.join(); }
     } ifr;
+    int bb_steps = 1000;                   // option final_minimiser_steps: two-point steps before FIRE takes the stage over
+    bool final_bb = true;                  // option final_minimiser: 1 = stages of kind 5 start with the two-point step-size minimiser, 0 = they are FIRE stages
     int prefetch_ranks = 1;                // option prefetch_ranks: 0 = no helper thread (measurement knob)
     unsigned* h_tmo_dev = nullptr;         // its device address
 
@@ -312,11 +314,18 @@ void build_program(c3d_ctx* c) {
     int prev_kind = -1;
     for (size_t s = 0; s < c->stages.size(); ++s) {
         const c3d_stage& st = c->stages[s];
-        if (st.kind == 2) {
-            for (int k = 0; k < st.nsteps; ++k)   // kind 3 = first step of the stage (fresh FIRE state)
-                c->program.push_back({dev_step(c, k == 0 ? 3 : 2, 0.0f, st.w_all, st.w_vdw, st.repel_s, 0.0f), (int)s, true});
+        if (st.kind == 2 || st.kind == 5) {
+            // kind 3 / 6 = first step of a minimiser's run (fresh state).  A stage of kind 5 starts with the two-point step-size minimiser
+            // (kinds 6 / 5) and hands over to FIRE (3 / 2) after bb_steps of them if the exit test has not ended the stage by then: the
+            // two-point method has no descent guarantee — one replica in a few hundred ends in a cycle of long moves instead of a minimum —
+            // and FIRE finishes what it leaves (the CPU restatement does the same: c3o_run_schedule).  Option final_minimiser = 0: kind 5 runs as FIRE throughout.
+            const int nbb = st.kind == 5 && c->final_bb ? std::min(st.nsteps, c->bb_steps) : 0;
+            for (int k = 0; k < st.nsteps; ++k) {
+                const int kind = k < nbb ? (k == 0 ? 6 : 5) : (k == nbb ? 3 : 2);
+                c->program.push_back({dev_step(c, kind, 0.0f, st.w_all, st.w_vdw, st.repel_s, 0.0f), (int)s, true});
+            }
         } else {
-            if (prev_kind == 2 || prev_kind == -1)
+            if (prev_kind == 2 || prev_kind == 5 || prev_kind == -1)
                 c->program.push_back({dev_step(c, 4, 0.0f, st.w_all, st.w_vdw, st.repel_s, st.t_bath), (int)s, false});
             for (int k = 0; k < st.nsteps; ++k)
                 c->program.push_back({dev_step(c, st.kind, st.dt, st.w_all, st.w_vdw, st.repel_s, st.t_bath), (int)s, true});
@@ -614,7 +623,8 @@ int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w) {
             const Op& first = c->program[c->pc];
             const Op& last = c->program[c->pc + chunk - 1];
             long sig = (long)c->pc;
-            if (first.p.kind == 2 && last.p.kind == 2 && first.stage == last.stage) sig = -(long)(first.stage + 1);
+            if ((first.p.kind == 2 || first.p.kind == 5) && last.p.kind == first.p.kind && first.stage == last.stage)
+                sig = -(long)(first.stage + 1) - (first.p.kind == 5 ? 1000000L : 0L);     // (a stage of kind 5 has a two-point part and a FIRE part)
             if (c->graphs.size() >= 2048) {                        // bounded: a caller with ever new ranges starts over
                 for (int g = 0; g < G; ++g) HIP_TRY(hipStreamSynchronize(c->gstream[g]));
                 drop_graphs(c);
@@ -794,8 +804,8 @@ extern "C" int c3d_default_schedule(c3d_stage* st, int cap, int min_steps) {
         kv = std::min(4.0, kv * vdw_step);
         bath -= 25.0;
     }
-    // final minimisation (deck :1790-1803): weights * 1
-    v.push_back({2, min_steps, 0.0f, 1.0f, 1.0f, 0.85f, 0.0f});
+    // final minimisation (deck :1790-1803): weights * 1; kind 5 = two-point step-size minimiser, FIRE after final_minimiser_steps (round 5)
+    v.push_back({5, min_steps, 0.0f, 1.0f, 1.0f, 0.85f, 0.0f});
     if (st) for (int k = 0; k < (int)v.size() && k < cap; ++k) st[k] = v[k];
     return (int)v.size();
 }
@@ -909,7 +919,7 @@ extern "C" int c3d_set_schedule(c3d_ctx* c, const c3d_stage* st, int n_stages, c
                                 int check_every) {
     if (!c || !st || n_stages < 1) return fail(C3D_ERR_INVALID, "c3d_set_schedule: bad arguments");
     for (int k = 0; k < n_stages; ++k)
-        if (st[k].kind < 0 || st[k].kind > 2 || st[k].nsteps < 0) return fail(C3D_ERR_INVALID, "c3d_set_schedule: bad stage");
+        if (st[k].kind < 0 || (st[k].kind > 2 && st[k].kind != 5) || st[k].nsteps < 0) return fail(C3D_ERR_INVALID, "c3d_set_schedule: bad stage");
     c->stages.assign(st, st + n_stages);
     if (fire) c->fire = *fire;
     c->gtol = gtol;
@@ -968,6 +978,18 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
     if (!strcmp(key, "cluster_inject_incomplete")) { c->inject_incomplete = value != 0; return C3D_OK; }   // test hook
     if (!strcmp(key, "cluster_num_xcc")) { c->num_xcc = (int)value; free_replica_buffers(c); return C3D_OK; }   // test hook: pretend a partitioned device
     if (!strcmp(key, "prefetch_ranks")) { c->prefetch_ranks = value != 0; return C3D_OK; }
+    if (!strcmp(key, "final_minimiser_steps")) {
+        if (value < 2) return fail(C3D_ERR_INVALID, "c3d_set_option: final_minimiser_steps >= 2");
+        c->bb_steps = (int)value;
+        if (!c->stages.empty()) build_program(c);
+        return C3D_OK;
+    }
+    if (!strcmp(key, "final_minimiser")) {       // what a stage of kind 5 runs: 1 (default) two-point step size then FIRE, 0 FIRE throughout
+        if (value != 0 && value != 1) return fail(C3D_ERR_INVALID, "c3d_set_option: final_minimiser is 0 (FIRE) or 1 (two-point step size)");
+        c->final_bb = value != 0;
+        if (!c->stages.empty()) build_program(c);
+        return C3D_OK;
+    }
     if (!strcmp(key, "cluster_xcd_count")) {      // 1..8 XCDs for this context's multi-step launches; re-plans: before c3d_init_replicas
         const int v = (int)value;
         if (v < 1 || v > 8 || c->xcd_base + v > 8) return fail(C3D_ERR_INVALID, "cluster_xcd_count: 1..8, and cluster_xcd_base + cluster_xcd_count <= 8");
@@ -1369,7 +1391,7 @@ extern "C" int c3d_run(c3d_ctx* c) {
     int rc = begin_timing(c);
     if (rc) return rc;
     const int last_stage = (int)c->stages.size() - 1;
-    const bool early = c->gtol > 0.0f && last_stage >= 0 && c->stages[last_stage].kind == 2;
+    const bool early = c->gtol > 0.0f && last_stage >= 0 && (c->stages[last_stage].kind == 2 || c->stages[last_stage].kind == 5);
     // everything before the final minimisation
     size_t nfixed = c->program.size() - c->pc;
     if (early) {

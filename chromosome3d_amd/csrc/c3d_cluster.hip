@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
       if (run != run0) cur = runs[run];
       const DevStep p = cur.p;
       const int count = cur.count;
-      const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
+      const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2 || p.kind == 5;
       for (int it = run == run0 ? skip0 : 0; it < count; ++it, ++s) {
 #ifdef C3D_STAMPS
         if (cstamper && s == 0) g_pstamps[7] = __builtin_amdgcn_s_memrealtime();
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             }
         } else if constexpr (ROLE == 1) {
             // ---- replica sums of the previous step -> scalars of this one (only H0 needs them) -----------
-            if (p.kind != 2) { st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0; }
+            if (p.kind != 2 && p.kind != 5) { st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0; }
             float4 psum = make_float4(0, 0, 0, 0);
             if (needs_partials) {
                 if (late && !solo && s > 0) {
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                         Fz = row_total<false>(pk, sz, cz);
                     }
                     float vx0 = vcx, vy0 = vcy, vz0 = vcz;
-                    if constexpr (K == 3) { vx0 = vy0 = vz0 = 0.0f; }
+                    if constexpr (K == 3 || K == 6) { vx0 = vy0 = vz0 = 0.0f; }
                     else if constexpr (K == 4) { C3D_HROW_INDEX; const float* vinit = io.vinit; vx0 = vinit[ix]; vy0 = vinit[iy]; vz0 = vinit[iz]; }
                     finish_row(m, pk, fp, sc, st, Fx, Fy, Fz, hx0, hy0, hz0, vx0, vy0, vz0, xn, yn, zn, vcx, vcy, vcz, q);
                     if (!last && !solo) {               // the row's new position leaves at once; the tile sums follow below
@@ -435,6 +435,8 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 case 1: row_update(std::integral_constant<int, 1>{}); break;
                 case 2: row_update(std::integral_constant<int, 2>{}); break;
                 case 3: row_update(std::integral_constant<int, 3>{}); break;
+                case 5: row_update(std::integral_constant<int, 5>{}); break;
+                case 6: row_update(std::integral_constant<int, 6>{}); break;
                 default: row_update(std::integral_constant<int, 4>{}); break;
             }
             // B3 (see the other roles below): the rows are out; what follows here — tile sums, their two units — is wanted by the

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
     const bool fin_lane = lane < RPW;
     const bool finisher = fin_lane && row < m.n;
     const size_t ix = roff + row, iy = ix + npad, iz = iy + npad;
-    const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
+    const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2 || p.kind == 5;
 
     // ---- 1. every independent global load is issued before anything waits -------------------
     if (m.stage_dma) lds_dma_copy<BLOCK>(xin + roff, smem, 3 * npad, tid);
@@ -122,13 +122,13 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
         else tile_prefetch<RPW, NC>(m, tgt, row0, lane, 0, tv);
     }
     float vx0 = 0.0f, vy0 = 0.0f, vz0 = 0.0f;
-    if (finisher && p.kind != 3) {
+    if (finisher && p.kind != 3 && p.kind != 6) {
         const float* vsrc = p.kind == 4 ? vinit : vin;
         vx0 = vsrc[ix]; vy0 = vsrc[iy]; vz0 = vsrc[iz];
     }
     FireState st;
     st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0;
-    if (p.kind == 2) st = sin[rep];
+    if (p.kind == 2 || p.kind == 5) st = sin[rep];
     // WIDE (large N: hundreds of tile sums): ONE wave of the workgroup forms the replica sums and the step's scalars and hands them to the
     // others through LDS across the barrier that waits for the coordinates anyway — the same values, the same bits (every wave used to
     // derive them for itself: ~90 of a wave's ~2200 VALU instructions per step at N = 2500, three quarters of them redundant)
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * TR / RPW) __attribute__((amdgpu_waves_per_eu(W
     if (sums_here) {
         if (needs_partials) psum = wave_sum4(psum);
         sc = step_scalars(m, p, fp, psum, st);
-        if ((p.kind == 2 || p.kind == 3) && tile == 0 && tid == 0) sout[rep] = st;
+        if ((p.kind == 2 || p.kind == 3 || p.kind == 5 || p.kind == 6) && tile == 0 && tid == 0) sout[rep] = st;
         if constexpr (SHARE) {
             if (lane == 0) {
                 scb[0] = sc.lam; scb[1] = sc.cmx; scb[2] = sc.cmy; scb[3] = sc.cmz; scb[4] = sc.keep; scb[5] = sc.mix;

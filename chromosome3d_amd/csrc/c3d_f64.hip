@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
     double ta0 = Ta[0], ta1 = Ta[64], tb0 = Tb[0], tb1 = Tb[64];        // np >= 128: in bounds whatever n is
     const int row = row0 + lane;
     double v0x = 0, v0y = 0, v0z = 0;
-    if (lane < kRows64 && row < n && p.kind != 3) {
+    if (lane < kRows64 && row < n && p.kind != 3 && p.kind != 6) {
         const double* vsrc = p.kind == 4 ? vinit : vin;
         const size_t ix = roff + row;
         v0x = vsrc[ix]; v0y = vsrc[ix + np]; v0z = vsrc[ix + 2 * np];
@@ -250,9 +250,9 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
     double* scal = rowq + 4 * kTileRows;                // [8] lam, cm0, cm1, cm2, keep, mix, dt, (unused)
     FireState64 st;
     st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0;
-    if (wave == 0 && p.kind == 2) st = sin[rep];        // (asked for here, used after the sums have arrived)
+    if (wave == 0 && (p.kind == 2 || p.kind == 5)) st = sin[rep];        // (asked for here, used after the sums have arrived)
     if (wave == 0) {
-        const bool needs = p.kind == 0 || p.kind == 1 || p.kind == 2;
+        const bool needs = p.kind == 0 || p.kind == 1 || p.kind == 2 || p.kind == 5;
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         if (needs) {
             const double* pp = pin + (size_t)rep * m.ntiles * 4;
@@ -279,6 +279,20 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
             } else {
                 st.alpha = fp.alpha_start; st.dt *= fp.f_dec; st.npos = 0;
             }
+            if (tile == 0 && lane == 0) sout[rep] = st;
+        } else if (p.kind == 5 || p.kind == 6) {        // two-point step size, the length one evaluation late (c3o_bb_step): lam = previous length, mix = this one
+            const int k = p.kind == 6 ? 0 : st.npos;
+            const double a_prev = st.dt;
+            double a = a_prev;
+            if (k == 0) a = fp.dt_start * fp.dt_start * p.kacc;
+            else if (k >= 2) {
+                if (s0 > 0) a = (k & 1) ? s0 * rcp64(s2) : s3 * rcp64(s0);
+                else a = 2.0 * a_prev;
+                if (!(a >= 1e-7)) a = 1e-7;
+                if (a > 1e2) a = 1e2;
+            }
+            lam = a_prev; mix = a;
+            st.dt = a; st.npos = k + 1;
             if (tile == 0 && lane == 0) sout[rep] = st;
         }
         if (lane == 0) { scal[0] = lam; scal[1] = cm0; scal[2] = cm1; scal[3] = cm2; scal[4] = keep; scal[5] = mix; scal[6] = st.dt; }
@@ -366,6 +380,25 @@ __global__ __launch_bounds__(kBlock64) __attribute__((amdgpu_waves_per_eu(5))) v
             vx = lam * (v0x - cm0) + acc * Fx; vy = lam * (v0y - cm1) + acc * Fy; vz = lam * (v0z - cm2) + acc * Fz;
             xn = x0 + p.dt * vx; yn = y0 + p.dt * vy; zn = z0 + p.dt * vz;
             q0 = vx * vx + vy * vy + vz * vz; q1 = vx; q2 = vy; q3 = vz;
+        } else if (p.kind == 5 || p.kind == 6) {
+            const double ms2 = fp.max_step * fp.max_step;
+            auto clamp_scale = [&](double d2) {
+                double scl = 1.0;
+                if (d2 > ms2) { double dd, hh; sqrt_hrsqrt64(d2, dd, hh); hh = fma(fma(-dd, hh, 0.5), hh, hh); scl = fp.max_step * (hh + hh); }
+                return scl;
+            };
+            q1 = Fx * Fx + Fy * Fy + Fz * Fz;
+            if (p.kind == 5) {
+                double sx = lam * v0x, sy = lam * v0y, sz = lam * v0z;
+                const double scp = clamp_scale(sx * sx + sy * sy + sz * sz);
+                sx *= scp; sy *= scp; sz *= scp;
+                const double yx = v0x - Fx, yy = v0y - Fy, yz = v0z - Fz;
+                q0 = sx * yx + sy * yy + sz * yz; q2 = yx * yx + yy * yy + yz * yz; q3 = sx * sx + sy * sy + sz * sz;
+            }
+            const double dxs = mix * Fx, dys = mix * Fy, dzs = mix * Fz;
+            const double scl = clamp_scale(dxs * dxs + dys * dys + dzs * dzs);
+            xn = x0 + scl * dxs; yn = y0 + scl * dys; zn = z0 + scl * dzs;
+            vx = Fx; vy = Fy; vz = Fz;
         } else {
             q0 = v0x * Fx + v0y * Fy + v0z * Fz; q1 = Fx * Fx + Fy * Fy + Fz * Fz; q2 = v0x * v0x + v0y * v0y + v0z * v0z;
             const double acc = st.dt * p.kacc;

@@ -48,7 +48,8 @@ struct DevModel {
 };
 
 struct DevStep {
-    int kind;        // 0 MD T-coupling, 1 MD velocity rescale, 2 FIRE step, 3 first FIRE step of a stage, 4 MD begin
+    int kind;        // 0 MD T-coupling, 1 MD velocity rescale, 2 FIRE step, 3 first FIRE step of a stage, 4 MD begin,
+                     // 5 two-point step-size (Barzilai-Borwein) minimiser step, 6 its first step of a stage
     float dt;
     float w_all;     // weights * w
     float w_noe2n;   // -2 * w_all * s_noe

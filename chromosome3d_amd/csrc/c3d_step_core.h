@@ -782,6 +782,7 @@ struct StepScalars {
 };
 // psum: MD kinds 0/1 = (sum v^2, sum vx, sum vy, sum vz) of the previous half step;
 //       FIRE kind 2 = (v.F, F.F, v.v) of the previous evaluation; kind 3 (first step of a stage) = 0, fresh state
+//       two-point step size kind 5 = (s.y, F.F, y.y, s.s) of the previous evaluation; kind 6 (first step of a stage) = nothing, fresh state
 __device__ __forceinline__ StepScalars step_scalars(const DevModel& m, const DevStep& p, const DevFire& fp, const float4 psum,
                                                     FireState& st) {
     StepScalars s;
@@ -799,6 +800,21 @@ __device__ __forceinline__ StepScalars step_scalars(const DevModel& m, const Dev
         // products that a subtraction follows (finish_row: v - v_cm): hidden from the instruction selector, so that "product, then difference"
         // is what every kernel computes whatever the backend would like to fuse under -ffp-contract=fast (see row_total)
         asm("" : "+v"(s.cmx), "+v"(s.cmy), "+v"(s.cmz));
+    } else if (p.kind == 5 || p.kind == 6) {
+        // two-point step size (Barzilai-Borwein) with the length one evaluation late (the CPU restatement: c3o_bb_step): lam = the length of the previous
+        // move (to rebuild it from the force kept in the velocity slot), mix = the length of this one; st.dt / st.npos carry them on
+        const int k = p.kind == 6 ? 0 : st.npos;
+        const float a_prev = st.dt;
+        float a = a_prev;
+        if (k == 0) a = fp.dt_start * fp.dt_start * m.acc;
+        else if (k >= 2) {
+            const float sy = psum.x;
+            if (sy > 0.0f) a = (k & 1) ? sy * __builtin_amdgcn_rcpf(psum.z) : psum.w * __builtin_amdgcn_rcpf(sy);
+            else a = 2.0f * a_prev;
+            a = fminf(fmaxf(a, 1e-7f), 1e2f);
+        }
+        s.lam = a_prev; s.mix = a;
+        st.dt = a; st.npos = k + 1;
     } else if (p.kind == 2 || p.kind == 3) {
         // FIRE (Bitzek et al. 2006) with the power test on the previous step's sums
         if (psum.x > 0.0f) {
@@ -839,6 +855,26 @@ __device__ __forceinline__ void finish_row(const DevModel& m, const DevStep& p, 
             zn = fmaf(p.dt, vz, z0);
         }
         q = make_float4(fmaf(vx, vx, fmaf(vy, vy, vz * vz)), vx, vy, vz);
+    } else if (p.kind == 5 || p.kind == 6) {
+        // v0 = the force of the previous evaluation; the previous move is rebuilt from it (same clamp), y = F_old - F
+        const float ms2 = fp.max_step * fp.max_step;
+        const float ff = fmaf(Fx, Fx, fmaf(Fy, Fy, Fz * Fz));
+        if (p.kind == 5) {
+            float sx = sc.lam * vx0, sy = sc.lam * vy0, sz = sc.lam * vz0;
+            const float s2 = fmaf(sx, sx, fmaf(sy, sy, sz * sz));
+            const float scp = s2 > ms2 ? fp.max_step * __builtin_amdgcn_rsqf(s2) : 1.0f;
+            sx *= scp; sy *= scp; sz *= scp;
+            asm("" : "+v"(sx), "+v"(sy), "+v"(sz));          // (products, then sums of products: kept apart in every build, see row_total)
+            const float yx = vx0 - Fx, yy = vy0 - Fy, yz = vz0 - Fz;
+            q = make_float4(fmaf(sx, yx, fmaf(sy, yy, sz * yz)), ff, fmaf(yx, yx, fmaf(yy, yy, yz * yz)), fmaf(sx, sx, fmaf(sy, sy, sz * sz)));
+        } else {
+            q = make_float4(0.0f, ff, 0.0f, 0.0f);
+        }
+        const float dxs = sc.mix * Fx, dys = sc.mix * Fy, dzs = sc.mix * Fz;
+        const float d2 = fmaf(dxs, dxs, fmaf(dys, dys, dzs * dzs));
+        const float scl = d2 > ms2 ? fp.max_step * __builtin_amdgcn_rsqf(d2) : 1.0f;
+        xn = fmaf(scl, dxs, x0); yn = fmaf(scl, dys, y0); zn = fmaf(scl, dzs, z0);
+        vx = Fx; vy = Fy; vz = Fz;
     } else {
         // sums of THIS evaluation for the next step's test, with the velocity that led here
         q = make_float4(fmaf(vx0, Fx, fmaf(vy0, Fy, vz0 * Fz)), fmaf(Fx, Fx, fmaf(Fy, Fy, Fz * Fz)),

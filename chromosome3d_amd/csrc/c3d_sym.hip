@@ -130,10 +130,10 @@ __global__ __launch_bounds__(64) void k_update_sym(const float* __restrict__ pin
     const bool live = row < m.n;
     const size_t roff = (size_t)rep * 3 * npad;
     const float* X = xin + roff;
-    const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2;
+    const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2 || p.kind == 5;
     FireState st;
     st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0;
-    if (p.kind == 2) st = sin[rep];
+    if (p.kind == 2 || p.kind == 5) st = sin[rep];
     float4 psum = make_float4(0, 0, 0, 0);
     if (needs_partials) {
         const float4* pp = reinterpret_cast<const float4*>(pin) + (size_t)rep * m.ntiles;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void k_update_sym(const float* __restrict__ pin
         psum.w = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(psum.w)));
     }
     const StepScalars sc = step_scalars(m, p, fp, psum, st);
-    if ((p.kind == 2 || p.kind == 3) && blockIdx.x == 0 && lane == 0) sout[rep] = st;
+    if ((p.kind == 2 || p.kind == 3 || p.kind == 5 || p.kind == 6) && blockIdx.x == 0 && lane == 0) sout[rep] = st;
 
     float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
     if (p.kind != 4 && live) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_update_sym(const float* __restrict__ pin
     if (live) {
         const size_t ix = roff + row, iy = ix + npad, iz = iy + npad;
         float vx0 = 0.0f, vy0 = 0.0f, vz0 = 0.0f;
-        if (p.kind != 3) { const float* vsrc = p.kind == 4 ? vinit : vin; vx0 = vsrc[ix]; vy0 = vsrc[iy]; vz0 = vsrc[iz]; }
+        if (p.kind != 3 && p.kind != 6) { const float* vsrc = p.kind == 4 ? vinit : vin; vx0 = vsrc[ix]; vy0 = vsrc[iy]; vz0 = vsrc[iz]; }
         float vx, vy, vz, xn, yn, zn;
         finish_row(m, p, fp, sc, st, Fx, Fy, Fz, X[row], X[npad + row], X[2 * npad + row], vx0, vy0, vz0, xn, yn, zn, vx, vy, vz, q);
         xout[ix] = xn; xout[iy] = yn; xout[iz] = zn;

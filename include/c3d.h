@@ -68,7 +68,13 @@ typedef struct {
 /* One stage of the annealing schedule (defaults: c3d_default_schedule, which restates
  * chromosome3D.pl:1631-1700 hot stages, :1729-1782 slow cool, :1790-1803 minimisation). */
 typedef struct {
-    int32_t kind;      /* 0 MD + T-coupling, 1 MD + velocity rescale, 2 FIRE minimise    */
+    int32_t kind;      /* 0 MD + T-coupling, 1 MD + velocity rescale, 2 FIRE minimise,
+                          5 minimise with two-point (Barzilai-Borwein) step sizes — one force evaluation a step, no energy, the length
+                            of a move = the inverse of a one-number curvature estimate from the previous move and the change of the force
+                            over it, taken one evaluation late (the replica sums of a step reach the next one) — for the first
+                            `final_minimiser_steps` (1000) steps, then FIRE for what is left of nsteps: half the evaluations FIRE needs
+                            to the same exit test, the same minima; the default schedule's final stage since round 5
+                            (option final_minimiser = 0: a stage of kind 5 is a FIRE stage)                                        */
     int32_t nsteps;
     float dt;          /* ps (MD)                                                        */
     float w_all;       /* `weights * w`                                                  */
@@ -153,6 +159,9 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *                   pairs |i-j| >= 3, spearman_IF_pdb.pl:30-44: 5 ms of host time at N = 455) on a helper thread over a copy of the matrix;
  *                   c3d_score_replicas takes it when its IF argument holds the same numbers, else computes it as before.  Same result
  *                   either way (measurement knob; stat "rank_prefetch_hits")
+ *   final_minimiser 1 (default) / 0: what a stage of kind 5 (the default schedule's final stage) runs — two-point step sizes handing over to
+ *                   FIRE after final_minimiser_steps, or FIRE throughout as in rounds 1-4.  Stages of kind 2 are FIRE whatever this says
+ *   final_minimiser_steps   1000 (default): two-point steps of a kind-5 stage before FIRE takes it over (>= 2)
  *   start           0 (default) random coil, 1 extended strand (chromosome3D.pl:2413-2416)
  *   use_graph       != 0: per-step path replays hipGraphs (default 1)
  *   replica_groups  1..4 stream groups of the per-step path (default 2);  graph_chunk, rows_per_wave,

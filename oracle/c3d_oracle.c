@@ -250,7 +250,7 @@ typedef struct {
 } c3o_model;
 
 typedef struct {
-    int kind;         /* 0 MD + Berendsen T-coupling, 1 MD + velocity rescale, 2 FIRE minimise */
+    int kind;         /* 0 MD + Berendsen T-coupling, 1 MD + velocity rescale, 2 FIRE minimise, 5 two-point step-size minimise (c3o_bb_step), FIRE after g_two_point_steps of them */
     int nsteps;
     double dt;        /* ps */
     double w_all;     /* `weights * w`            */
@@ -489,6 +489,60 @@ void c3o_fire_step(const c3o_model* m, const int32_t* tgt10, const c3o_stage* st
     L[0] = vf; L[1] = ff; L[2] = vv;
 }
 
+/* One step of the two-point step-size (Barzilai-Borwein 1988) minimiser in the form the device runs it — stage kind 5, round 5's
+ * opt-in alternative to FIRE for the final minimisation (deck chromosome3D.pl:1790-1803 runs L-BFGS there; this is the scalar,
+ * memoryless member of the same secant family: the step length is the inverse of a one-number curvature estimate from the last
+ * move s and the change of the gradient y over it).  One force evaluation a step, no energy, no line search:
+ *   F = F(x_k);   s = the previous move (a_prev F_old, per-bead clamp max_step),  y = F_old - F (the gradient is -F);
+ *   this step's sums  L' = (s.y, F.F, y.y, s.s);
+ *   the length of THIS move comes from the sums L of the PREVIOUS evaluation (the device's one-step lag, as in c3o_fire_step:
+ *   a "gradient method with retards", Friedlander et al. 1999): s.y > 0: a = s.s / s.y on even evaluations, s.y / y.y on odd ones
+ *   (the two Barzilai-Borwein lengths, alternated); s.y <= 0 (negative curvature along the move): twice the previous length;
+ *   kept inside [1e-7, 1e2];  evaluations 0 and 1 of a stage, which have no completed pair yet, move with
+ *   a0 = dt_start^2 ACCEL / mass (FIRE's first displacement per unit force);
+ *   x += clamp(a F) per bead, F_old = F (kept in the velocity array), L = L'.
+ * fs->dt holds the length of the last move, fs->npos the evaluation count of the stage. */
+void c3o_bb_step(const c3o_model* m, const int32_t* tgt10, const c3o_stage* st, const c3o_fire_params* fp,
+                 c3o_fire_state* fs, double* L, double* x, double* v, double* F) {
+    const int n = m->n;
+    c3o_energy_force(m, tgt10, x, st->w_all, st->w_vdw, st->repel_s, F, NULL);
+    const int k = fs->npos;
+    const double a_prev = fs->dt;
+    double a = a_prev;
+    if (k == 0) a = fp->dt_start * fp->dt_start * ACCEL / m->mass;
+    else if (k >= 2) {
+        const double sy = L[0];
+        if (sy > 0) a = (k % 2 == 0) ? L[3] / sy : sy / L[2];
+        else a = 2.0 * a_prev;
+        if (!(a >= 1e-7)) a = 1e-7;
+        if (a > 1e2) a = 1e2;
+    }
+    double q[4] = {0, 0, 0, 0};
+    const double ms2 = fp->max_step * fp->max_step;
+    for (int i = 0; i < n; ++i) {
+        double s[3] = {0, 0, 0}, d2 = 0;
+        if (k > 0) {
+            for (int c = 0; c < 3; ++c) { s[c] = a_prev * v[3 * i + c]; d2 += s[c] * s[c]; }
+            const double sc = d2 > ms2 ? fp->max_step / sqrt(d2) : 1.0;
+            for (int c = 0; c < 3; ++c) {
+                s[c] *= sc;
+                const double y = v[3 * i + c] - F[3 * i + c];
+                q[0] += s[c] * y; q[2] += y * y; q[3] += s[c] * s[c];
+            }
+        }
+        double dr[3];
+        d2 = 0;
+        for (int c = 0; c < 3; ++c) { q[1] += F[3 * i + c] * F[3 * i + c]; dr[c] = a * F[3 * i + c]; d2 += dr[c] * dr[c]; }
+        const double sc = d2 > ms2 ? fp->max_step / sqrt(d2) : 1.0;
+        for (int c = 0; c < 3; ++c) { x[3 * i + c] += sc * dr[c]; v[3 * i + c] = F[3 * i + c]; }
+    }
+    fs->dt = a; fs->npos = k + 1;
+    for (int c = 0; c < 4; ++c) L[c] = q[c];
+}
+
+static int g_two_point_steps = 1000;     /* device option final_minimiser_steps */
+void c3o_set_two_point_steps(int k) { g_two_point_steps = k < 2 ? 2 : k; }
+
 /* Run a schedule of stages on one replica.  x (n*3) in/out, v scratch (n*3).
  * Returns number of force evaluations.  If gtol > 0, a FIRE stage exits when the RMS force
  * drops below gtol (checked every `check_every` steps, as the device path does). */
@@ -502,17 +556,27 @@ long c3o_run_schedule(const c3o_model* m, const int32_t* tgt10, const c3o_stage*
     int prev_kind = -1;
     for (int s = 0; s < n_stages; ++s) {
         const c3o_stage* st = &stages[s];
-        if (st->kind == 2) {
+        if (st->kind == 2 || st->kind == 5) {
+            /* kind 5: two-point steps for the first g_two_point_steps evaluations of the stage, then FIRE from a fresh state (v = 0) for
+             * the rest — the two-point method has no descent guarantee, FIRE takes over what it has not finished (device: build_program) */
             c3o_fire_state fs = {fp->dt_start, fp->alpha_start, 0, 1};
-            double L[3] = {0, 0, 0};
+            double L[4] = {0, 0, 0, 0};
+            const int nbb = st->kind == 5 ? (st->nsteps < g_two_point_steps ? st->nsteps : g_two_point_steps) : 0;
             for (int k = 0; k < 3 * n; ++k) v[k] = 0;
             for (int it = 0; it < st->nsteps; ++it) {
-                c3o_fire_step(m, tgt10, st, fp, &fs, L, x, v, F);
+                if (it == nbb && nbb > 0) {
+                    const c3o_fire_state fresh = {fp->dt_start, fp->alpha_start, 0, 1};
+                    fs = fresh;
+                    L[0] = L[1] = L[2] = L[3] = 0;
+                    for (int k = 0; k < 3 * n; ++k) v[k] = 0;
+                }
+                if (it >= nbb) c3o_fire_step(m, tgt10, st, fp, &fs, L, x, v, F);
+                else c3o_bb_step(m, tgt10, st, fp, &fs, L, x, v, F);
                 ++evals;
                 if (gtol > 0 && check_every > 0 && (it + 1) % check_every == 0 && sqrt(L[1] / (3.0 * n)) < gtol) break;
             }
         } else {
-            if (prev_kind == 2 || prev_kind == -1) c3o_init_velocities(m, seed, replica, 0.5, v);
+            if (prev_kind == 2 || prev_kind == 5 || prev_kind == -1) c3o_init_velocities(m, seed, replica, 0.5, v);
             for (int it = 0; it < st->nsteps; ++it) { c3o_md_step(m, tgt10, st, x, v, F); ++evals; }
         }
         prev_kind = st->kind;

@@ -77,6 +77,9 @@ def lib():
         L.c3o_run_schedule.argtypes = [C.POINTER(Model), i32p, C.POINTER(Stage), C.c_int, C.POINTER(FireParams),
                                        C.c_double, C.c_int, C.c_uint64, C.c_uint32, dp, dp]
         L.c3o_run_schedule.restype = C.c_long
+        L.c3o_set_two_point_steps.argtypes = [C.c_int]
+        L.c3o_set_two_point_steps.restype = None
+        L.c3o_bb_step.argtypes = [C.POINTER(Model), i32p, C.POINTER(Stage), C.POINTER(FireParams), C.POINTER(FireState), dp, dp, dp, dp]
         L.c3o_assess.argtypes = [dp, C.c_int, ip, ip, i32p, C.c_double, ip, dp]
         L.c3o_spearman_if_dist.argtypes = [dp, dp, C.c_int, C.c_int]
         L.c3o_spearman_if_dist.restype = C.c_double
@@ -186,6 +189,11 @@ def make_stages(rows):
     for k, r in enumerate(rows):
         arr[k] = Stage(*r)
     return arr
+
+
+def set_two_point_steps(k):
+    """Stage kind 5: evaluations of the two-point step-size minimiser before FIRE takes the stage over (device option final_minimiser_steps)."""
+    lib().c3o_set_two_point_steps(int(k))
 
 
 def run_schedule(model, tgt10, stages, fire, seed, replica, x0=None, gtol=0.0, check_every=0):

@@ -394,9 +394,37 @@ def test_final_minimisation_converges_at_the_headline_size(solver):
     assert solver.stat("rms_force") < 1e-2
 
 
+def test_final_stage_leaves_through_the_exit_test_on_every_bundled_matrix(solver):
+    """The shipped final stage (kind 5: two-point step sizes, FIRE after 1000 of them) with the product's exit test (RMS force < 1e-2,
+    every 250 steps), 20 replicas, all 45 matrices: every anneal leaves through the test, well before the stage's 3000 steps are used
+    up, and the two-point part alone ends most of them.  (FIRE throughout — rounds 1-4, option final_minimiser = 0 — used up all 3000
+    steps on 7 of 135 anneals over three seeds; this stage on none: scratch scan of round 5, profiles/r05_final_minimiser_ab.md.)"""
+    from chromosome3d_amd import default_fire, default_model, default_schedule, pipeline
+    steps = {}
+    for fm in (1, 0):
+        solver.set_option("final_minimiser", fm)
+        for cid in CIDS:
+            solver.set_model(default_model())
+            pipeline.IF2dist_new(solver, _load(cid))
+            solver.set_schedule(default_schedule(3000), default_fire(), 1e-2, 250)
+            solver.init_replicas(20, 82364, 0)
+            solver.run()
+            steps[(fm, cid)] = solver.last_timing()[1]
+            if fm:
+                assert solver.stat("rms_force") < 1e-2, cid
+    solver.set_option("final_minimiser", 1)
+    L = solver.schedule_length
+    two = np.array([steps[(1, c)] for c in CIDS]) - 2172
+    fire = np.array([steps[(0, c)] for c in CIDS]) - 2172
+    assert L == 5172 and (two <= 2000).all(), dict(zip(CIDS, two))
+    assert (two <= 1000).sum() >= 40 and two.sum() < 0.65 * fire.sum(), (two.sum(), fire.sum())      # measured: 0.52-0.55 of FIRE's steps
+
+
+@pytest.mark.parametrize("kind", [2, 5])
 @pytest.mark.parametrize("cid,nrep", [("chr21_1mb", 6), ("chr1_500kb", 4)])
-def test_device_fire_stage_ends_where_lbfgs_ends(solver, cid, nrep):
-    """The one hot-path stage whose ALGORITHM differs from the reference's by choice: `minimize lbfgs nstep=15000` x 10 (deck
+def test_device_fire_stage_ends_where_lbfgs_ends(solver, cid, nrep, kind):
+    """(kind 2: FIRE, the final stage of rounds 1-4; kind 5: the stage as shipped since round 5 — two-point step sizes, then FIRE.)
+    The one hot-path stage whose ALGORITHM differs from the reference's by choice: `minimize lbfgs nstep=15000` x 10 (deck
     chromosome3D.pl:1790-1803) is FIRE here.  From the device's own post-cooling coordinates, the device's final stage (the shipped fp32
     kernels, gradient exit) against L-BFGS (scipy L-BFGS-B, 10 correction pairs, up to 10 restarts like the deck's, on the CPU
     restatement's fp64 energy and gradient).  profiles/r05_fire_vs_lbfgs.txt (32 replicas, N = 37 .. 455): in 20 of 32 — all 8 at
@@ -410,6 +438,8 @@ def test_device_fire_stage_ends_where_lbfgs_ends(solver, cid, nrep):
     IF = _load(cid)
     n = IF.shape[0]
     rows = [(s.kind, s.nsteps, s.dt, s.w_all, s.w_vdw, s.repel_s, s.t_bath) for s in default_schedule(3000)]
+    assert rows[-1][0] == 5
+    rows[-1] = (kind,) + rows[-1][1:]
     m = default_model()
     solver.set_model(m)
     d10 = pipeline.IF2dist_new(solver, IF)

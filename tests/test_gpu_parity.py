@@ -336,6 +336,69 @@ def test_fire_short_trajectory(solver, O, cid):
         assert np.abs(xc - xo).max() < 2e-3, np.abs(xc - xo).max()
 
 
+@pytest.mark.parametrize("precision,tol", [(32, 5e-3), (64, 2e-5)])
+@pytest.mark.parametrize("cid", ["chr21_1mb", "chr20_1mb", "chr13_1mb"])
+def test_two_point_stage_short_trajectory(solver, O, cid, precision, tol):
+    """Stage kind 5 (round 5: the default schedule's final stage; c3d_step_core.h kinds 5 / 6, oracle c3o_bb_step): 40 FIRE steps from the
+    coil, then a kind-5 stage of 45 steps with the hand-over to FIRE after 20 of them — two-point steps, the hand-over and FIRE's fresh start
+    all inside the compared range; fp32 kernels and the fp64 path (measured: 2e-3 / 4e-6 A at worst)."""
+    stages = [(2, 40, 0.0, 1.0, 1.0, 0.85, 0.0), (5, 45, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    solver.set_option("precision", precision)
+    solver.set_option("final_minimiser_steps", 20)
+    O.set_two_point_steps(20)
+    try:
+        IF, d10, m, fire = _setup(solver, cid, stages, nrep=3)
+        x0 = solver.coords()
+        assert solver.run_steps(10 ** 6) == 85
+        x = solver.coords()
+        om, of = oracle_model_from(m, IF.shape[0]), oracle_fire_from(fire)
+        for r in range(3):
+            xo, _, ev = O.run_schedule(om, d10, O.make_stages(stages), of, 82364, r, x0=x0[r].astype(np.float64))
+            xc = x[r].astype(np.float64)
+            xc -= xc.mean(0)
+            assert ev == 85
+            assert np.abs(xc - xo).max() < tol, np.abs(xc - xo).max()
+    finally:
+        solver.set_option("precision", 32)
+        solver.set_option("final_minimiser_steps", 1000)
+        O.set_two_point_steps(1000)
+
+
+def test_final_minimiser_option_and_the_stage_kinds(solver):
+    """final_minimiser = 0 turns a stage of kind 5 into the FIRE stage of rounds 1-4 (the same bits as a schedule that says kind 2);
+    = 1 (default) gives other coordinates, the same minimum energies to 1e-6, in fewer steps; a stage of kind 2 is FIRE whatever the option
+    says; kinds 3, 4, 6 (internal) and anything else are refused."""
+    from chromosome3d_amd import C3DError, default_fire, default_model, default_schedule, make_stages, pipeline
+    IF = load_if("chr13_1mb")
+    rows = [(t.kind, t.nsteps, t.dt, t.w_all, t.w_vdw, t.repel_s, t.t_bath) for t in default_schedule(3000)]
+    assert rows[-1][0] == 5 and all(r[0] in (0, 1, 2) for r in rows[:-1])
+    as_fire = rows[:-1] + [(2,) + rows[-1][1:]]
+    out = {}
+    for name, sched, opt in (("five, option 1", rows, 1), ("five, option 0", rows, 0), ("two, option 1", as_fire, 1), ("two, option 0", as_fire, 0)):
+        solver.set_model(default_model())
+        pipeline.IF2dist_new(solver, IF)
+        solver.set_option("final_minimiser", opt)
+        solver.set_schedule(make_stages(sched), default_fire(), 1e-2, 250)
+        solver.init_replicas(6, 82364, 0)
+        solver.run()
+        out[name] = (solver.coords(), solver.energies(), solver.last_timing()[1])
+    solver.set_option("final_minimiser", 1)
+    fire = out["two, option 1"]
+    for name in ("five, option 0", "two, option 0"):
+        assert np.array_equal(out[name][0], fire[0]) and out[name][2] == fire[2], name
+    two_point = out["five, option 1"]
+    assert not np.array_equal(two_point[0], fire[0]) and two_point[2] < fire[2], (two_point[2], fire[2])
+    ea, eb = np.sort(two_point[1].sum(axis=1)), np.sort(fire[1].sum(axis=1))
+    assert np.abs(ea - eb).max() <= 1e-6 * eb.max(), (ea, eb)
+    for bad in (3, 4, 6, 7, -1):
+        with pytest.raises(C3DError):
+            solver.set_schedule(make_stages([(bad, 10, 0.0, 1.0, 1.0, 0.85, 0.0)]))
+    with pytest.raises(C3DError):
+        solver.set_option("final_minimiser", 2)
+    with pytest.raises(C3DError):
+        solver.set_option("final_minimiser_steps", 1)
+
+
 def test_headline_kernel_follows_the_oracle_at_the_headline_size(solver, O):
     """The kernel bench.py times — k_cluster at chr1_500kb x 20, whatever geometry the planner picks — against the oracle
     directly (not through its bit-identity with k_step): 20 MD steps at 2000 K and 20 FIRE steps in ONE multi-step launch,

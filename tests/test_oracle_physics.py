@@ -123,8 +123,10 @@ def test_philox_known_answer():
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def test_fire_and_lbfgs_reach_the_same_minimum():
-    """The final stage of the reference is `minimize lbfgs nstep=15000 drop=10` x 10 (deck chromosome3D.pl:1790-1803); here it is FIRE
+@pytest.mark.parametrize("kind", [2, 5])
+def test_fire_and_lbfgs_reach_the_same_minimum(kind):
+    """(kind 2: FIRE, the final stage of rounds 1-4; kind 5: the stage as shipped since round 5 — two-point step sizes, then FIRE.)
+    The final stage of the reference is `minimize lbfgs nstep=15000 drop=10` x 10 (deck chromosome3D.pl:1790-1803); here it is FIRE
     (one force evaluation per step, own-row data only).  A documented deviation in ALGORITHM, not in RESULT: from the same
     post-cooling state, FIRE (the restatement's, as the GPU runs it) and L-BFGS (scipy's L-BFGS-B, 10 correction pairs, on the
     restatement's energy and its analytic gradient — checked against a central difference first) end in the same minimum: total energy to
@@ -137,6 +139,8 @@ def test_fire_and_lbfgs_reach_the_same_minimum():
     d10 = O.if_to_dist10(IF)
     om, of = oracle_model_from(default_model(), n), oracle_fire_from(default_fire())
     rows = [(s.kind, s.nsteps, s.dt, s.w_all, s.w_vdw, s.repel_s, s.t_bath) for s in default_schedule(3000)]
+    assert rows[-1][0] == 5
+    rows[-1] = (kind,) + rows[-1][1:]
     w_all, w_vdw, rs = rows[-1][3], rows[-1][4], rows[-1][5]
 
     def fg(u):
@@ -164,3 +168,36 @@ def test_fire_and_lbfgs_reach_the_same_minimum():
         el = O.energy_force(om, d10, xl, w_all, w_vdw, rs)[1][0]
         assert abs(ef - el) < 1.0                                        # the ranking key is int(E_noe): chromosome3D.pl:796-802
         assert abs(pipeline.spearman_IF_pdb(IF, xf.astype(np.float32)) - pipeline.spearman_IF_pdb(IF, xl.astype(np.float32))) < 1e-4
+
+
+def test_two_point_stage_is_its_two_parts_and_reaches_the_fire_minimum():
+    """Stage kind 5 (round 5, the default schedule's final stage; c3o_bb_step): two-point step sizes for the first
+    `final_minimiser_steps`, then FIRE from a fresh state — the same as running the two parts as two stages; and from a half-relaxed
+    coil it reaches the exit test in about half of FIRE's evaluations and ends in FIRE's minimum or a lower neighbour."""
+    from chromosome3d_amd import default_fire, default_model
+    from tests.util import oracle_fire_from, oracle_model_from
+    IF = load_if("chr13_1mb")
+    n = IF.shape[0]
+    d10 = O.if_to_dist10(IF)
+    om, of = oracle_model_from(default_model(), n), oracle_fire_from(default_fire())
+    pre = O.make_stages([(2, 300, 0.0, 1.0, 1.0, 0.85, 0.0)])
+    tot = np.zeros(2)
+    try:
+        for r in range(4):
+            x0, _, _ = O.run_schedule(om, d10, pre, of, 82364, r)
+            O.set_two_point_steps(25)
+            xa, va, ea = O.run_schedule(om, d10, O.make_stages([(5, 70, 0.0, 1.0, 1.0, 0.85, 0.0)]), of, 82364, r, x0=x0)
+            O.set_two_point_steps(1000)
+            xb, vb, eb = O.run_schedule(om, d10, O.make_stages([(5, 25, 0.0, 1.0, 1.0, 0.85, 0.0), (2, 45, 0.0, 1.0, 1.0, 0.85, 0.0)]), of, 82364, r, x0=x0)
+            assert ea == eb == 70 and np.array_equal(xa, xb) and np.array_equal(va, vb)
+            xt, _, et = O.run_schedule(om, d10, O.make_stages([(5, 6000, 0.0, 1.0, 1.0, 0.85, 0.0)]), of, 82364, r, x0=x0, gtol=1e-2, check_every=10)
+            xf, _, ef = O.run_schedule(om, d10, O.make_stages([(2, 6000, 0.0, 1.0, 1.0, 0.85, 0.0)]), of, 82364, r, x0=x0, gtol=1e-2, check_every=10)
+            Ft, e_t = O.energy_force(om, d10, xt, 1.0, 1.0, 0.85)
+            tot += (et, ef)
+            # (the exit test sees the force BEFORE the last move, as on the device: after it the RMS may be a little above the bound)
+            assert np.sqrt((Ft * Ft).mean()) < 5e-2 and et < 6000 and ef < 6000
+            e_f = O.energy_force(om, d10, xf, 1.0, 1.0, 0.85)[1]
+            assert sum(e_t) <= sum(e_f) * (1 + 1e-4), (sum(e_t), sum(e_f))      # the same minimum (measured: three of four to 1e-8) or a lower neighbour
+        assert tot[0] < 0.7 * tot[1], tot                                    # measured: 1240 evaluations against 2440
+    finally:
+        O.set_two_point_steps(1000)

@@ -19,7 +19,7 @@ while time.time() - t0 < budget:
     n = int(rng.choice([int(rng.integers(1025, 1300)), int(rng.integers(1300, 2700)), int(rng.choice([1025, 1032, 1033, 1040, 1041, 1279, 1280, 1281, 2047, 2048, 2049, 2559, 2560]))]))
     nrep = int(rng.integers(1, 7))
     steps = [(2, int(rng.integers(2, 8)), 0.0, 1.0, 20.0, 0.5, 0.0), (0, int(rng.integers(4, 14)), 0.003, 0.4, 0.003, 0.9, 2000.0),
-             (1, int(rng.integers(2, 8)), 0.005, 1.0, 0.5, 0.9, 1000.0), (2, int(rng.integers(2, 8)), 0.0, 1.0, 1.0, 0.85, 0.0)]
+             (1, int(rng.integers(2, 8)), 0.005, 1.0, 0.5, 0.9, 1000.0), (int(rng.choice([2, 5])), int(rng.integers(2, 10)), 0.0, 1.0, 1.0, 0.85, 0.0)]    # (kind 5: two-point steps)
     total = sum(st[1] for st in steps)
     IF, _ = synthetic_if(n, seed=int(rng.integers(1, 10 ** 6)))
     out = {}

@@ -38,6 +38,9 @@ def all_cids():
 SCHED = dict(cool_mult=1, hot_mult=1)      # experiment knobs: the deck's step counts (chromosome3D.pl:1095-1097, :1741-1742) times these
 
 
+FINAL = {"minimiser": 1, "gtol": 0.0, "check_every": 250}     # override keys final_minimiser (0 = FIRE throughout, as rounds 1-4), gtol, check_every
+
+
 def schedule(min_steps):
     st = default_schedule(min_steps)
     for k in range(len(st)):
@@ -50,9 +53,10 @@ def schedule(min_steps):
 
 def solve(s, IF, over, nrep=20, seed=82364, min_steps=3000, embed=0, start=0):
     s.set_option("start", start)
+    s.set_option("final_minimiser", FINAL["minimiser"])
     s.set_model(default_model(**over))
     d10 = pipeline.IF2dist_new(s, IF)
-    s.set_schedule(schedule(min_steps), default_fire(), 0.0, 250)
+    s.set_schedule(schedule(min_steps), default_fire(), FINAL["gtol"], FINAL["check_every"])
     s.init_replicas(nrep, seed, 0)
     if embed:
         s.embed(50)
@@ -113,6 +117,7 @@ def main():
     nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     subset = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
     min_steps = int(over.pop("min_steps", 3000)); quiet = over.pop("quiet", 0); embed = over.pop("embed", 0)
+    FINAL["minimiser"] = int(over.pop("final_minimiser", 1)); FINAL["gtol"] = float(over.pop("gtol", 0.0)); FINAL["check_every"] = int(over.pop("check_every", 250))
     seed = int(over.pop("seed", 82364)); dump = over.pop("dump", None); start = int(over.pop("start", 0))
     SCHED["cool_mult"] = float(over.pop("cool_mult", 1)); SCHED["hot_mult"] = float(over.pop("hot_mult", 1))
     s = Solver(0)
@@ -141,7 +146,7 @@ def main():
             store[cid] = x; store[cid + "_e"] = e
         if not quiet:
             print(row(cid, IF.shape[0], s.num_restraints, rep, rank, ms), flush=True)
-    print(summary(reps) + f"; overrides {over}; schedule multipliers {SCHED}; start {'DG embed' if embed else ('extended strand' if start else 'random coil')}; seed {seed}; total {time.time() - t_all:.1f} s", flush=True)
+    print(summary(reps) + f"; overrides {over}; schedule multipliers {SCHED}; final stage {FINAL}; start {'DG embed' if embed else ('extended strand' if start else 'random coil')}; seed {seed}; total {time.time() - t_all:.1f} s", flush=True)
     if dump:
         np.savez_compressed(dump, **store)
 
