@@ -77,7 +77,7 @@ def cpu_baseline(IF, d10, model, fire, stages, budget_s=8.0):
     t0 = time.perf_counter()
     _, _, ev = O.run_schedule(om, d10, O.make_stages(sample), of, 82364, 0, x0=x)
     dt = time.perf_counter() - t0
-    kinds = "+".join(sorted({{0: "hot MD", 1: "cool MD", 2: "FIRE"}[r[0]] for r in sample}))
+    kinds = "+".join(sorted({{0: "hot MD", 1: "cool MD", 2: "FIRE", 5: "final minimisation (two-point steps)"}[r[0]] for r in sample}))
     one = (ev / dt, f"1 replica of {WORKLOAD}, {ev} SA steps of the same schedule after its first stage ({kinds}), fp64 oracle/c3d_oracle.c, "
                     f"1 core, {dt:.1f} s")
     # the same sample on every host core at once, one replica per thread (the reference's way to use a CPU box is one
@@ -518,7 +518,7 @@ def main():
             "data": "bundled Hi-C matrix chr1_500kb (tests/golden/inputs, exact float64 upper triangle); random-coil starts, seed 82364",
             "config": {"workload": f"{WORKLOAD}: N={n} beads, R={R} restraints, {total_replicas} replicas in all "
                                    f"({'+'.join(str(c) for c in per_rank)} per GPU), default schedule "
-                                   f"(200 FIRE + 1000 hot MD + 972 cool MD + {MIN_STEPS} FIRE = {L} SA steps)",
+                                   f"(200 FIRE + 1000 hot MD + 972 cool MD + {MIN_STEPS} final minimisation [1000 two-point steps, then FIRE; no early exit here] = {L} SA steps)",
                        "replicas_per_gpu": per_rank, "parallelism": f"replica-sharded x{world}",
                        "launch": {2: "one multi-step cluster launch per region", 0: "eager" if args.no_graph else "hipGraph",
                                   3: "fp64: one k64_step launch per step and replica group, hipGraph"}.get(path, "?")},
