@@ -106,7 +106,7 @@ if __name__ == "__main__":
     for cid in cids:
         IF = load_if(cid); n = IF.shape[0]
         rows = [(t.kind, t.nsteps, t.dt, t.w_all, t.w_vdw, t.repel_s, t.t_bath) for t in default_schedule(3000)]
-    rows[-1] = (2,) + rows[-1][1:]              # FIRE is what is compared here (the shipped final stage is kind 5 since round 5)
+        rows[-1] = (2,) + rows[-1][1:]              # FIRE is what is compared here (the shipped final stage is kind 5 since round 5)
         m = default_model(); s.set_model(m); d10 = pipeline.IF2dist_new(s, IF)
         s.set_schedule(make_stages(rows[:-1]), default_fire(), 0.0, 250); s.init_replicas(nrep, 82364, 0); s.run()
         x0 = s.coords()
