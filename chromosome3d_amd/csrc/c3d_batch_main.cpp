@@ -45,6 +45,7 @@ struct Job {
 struct Options {
     std::string out;
     double K = 11, alpha = 0.5, gtol = 1e-2;
+    int final_min = 1;          // --final-minimiser 0: FIRE throughout (rounds 1-4)
     int models = 20, min_steps = 3000;
     unsigned long long seed = 82364ULL;
     bool violations = false;       // --violations: also leave contact_violation.txt (:475-483; 180 MB of text per chromosome at N = 455)
@@ -120,6 +121,7 @@ bool solve_one(c3d_ctx* ctx, const Options& o, Job& job, XcdBroker& gpu) {
     c3d_default_schedule(stages.data(), (int)stages.size(), o.min_steps);
     c3d_fire_params fire;
     c3d_default_fire(&fire);
+    TRY(c3d_set_option(ctx, "final_minimiser", o.final_min));
     TRY(c3d_set_schedule(ctx, stages.data(), (int)stages.size(), &fire, (float)o.gtol, 250));
     // a chromosome for which a four-XCD geometry exists anneals on half of the device (chosen when its turn comes)
     bool half = false;
@@ -286,9 +288,10 @@ int main(int argc, char** argv) {
         else if (s == "--seed") o.seed = strtoull(next("--seed"), nullptr, 10);
         else if (s == "--min-steps") o.min_steps = atoi(next("--min-steps"));
         else if (s == "--gtol") o.gtol = atof(next("--gtol"));
+        else if (s == "--final-minimiser") o.final_min = atoi(next("--final-minimiser"));
         else if (s == "--pattern") pattern = next("--pattern");
         else if (s == "--violations") o.violations = true;
-        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--pattern text] [--violations] [--pair 1] [--order warm|lpt] [--map-devices-to P (rehearsal)]\n"); return 0; }
+        else if (s == "-h" || s == "--help") { printf("usage: c3d_batch <dir | matrix files...> --out <root> [--devices N] [--lanes 3] [-m 20] [-k 11] [-a 0.5] [--seed S] [--min-steps 3000] [--gtol 1e-2] [--final-minimiser 1] [--pattern text] [--violations] [--pair 1] [--order warm|lpt] [--map-devices-to P (rehearsal)]\n"); return 0; }
         else inputs.push_back(s);
     }
     if (o.out.empty() || inputs.empty() || o.models < 1) { fprintf(stderr, "c3d_batch: need input matrices and --out <root> (see --help)\n"); return 2; }

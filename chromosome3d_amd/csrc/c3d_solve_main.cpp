@@ -23,7 +23,7 @@ static void usage() {
     fprintf(stderr,
             "usage: c3d_solve (--if <IF matrix> | --tbl <contact.tbl> --n <beads>) --out <dir> [--id <ID>]\n"
             "                 [-k <K=11>] [-a <alpha=0.5>] [-m <models=20>] [--seed <82364>] [--first-replica <0>]\n"
-            "                 [--device <0>] [--min-steps <3000>] [--gtol <1e-2>] [--embed] [--no-graph] [--quiet]\n"
+            "                 [--device <0>] [--min-steps <3000>] [--gtol <1e-2>] [--final-minimiser <1>] [--embed] [--no-graph] [--quiet]\n"
             "                 [--seq <one-letter residue codes | @fasta file>   residue names of the models (default: all MET)]\n");
 }
 
@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
     const double t_start = now_s();
     std::string if_path, tbl_path, out_dir, id, seq_arg;
     double K = 11, alpha = 0.5, gtol = 1e-2;
+    int final_min = 1;
     int models = 20, device = 0, n_beads = 0, min_steps = 3000, use_graph = 1, quiet = 0, embed = 0;
     unsigned long long seed = 82364ULL;
     unsigned first_rep = 0;
@@ -73,6 +74,7 @@ int main(int argc, char** argv) {
         else if (s == "--device") device = atoi(next("--device"));
         else if (s == "--min-steps") min_steps = atoi(next("--min-steps"));
         else if (s == "--gtol") gtol = atof(next("--gtol"));
+        else if (s == "--final-minimiser") final_min = atoi(next("--final-minimiser"));   // 0 = FIRE throughout (rounds 1-4), 1 = two-point steps then FIRE (default)
         else if (s == "--embed") embed = 1;   // distance-geometry start (deck :1471-1525) instead of the random coil
         else if (s == "--no-graph") use_graph = 0;
         else if (s == "--quiet") quiet = 1;
@@ -135,6 +137,7 @@ int main(int argc, char** argv) {
     c3d_default_schedule(stages.data(), (int)stages.size(), min_steps);
     c3d_fire_params fire;
     c3d_default_fire(&fire);
+    CHECK(c3d_set_option(ctx, "final_minimiser", final_min));
     CHECK(c3d_set_schedule(ctx, stages.data(), (int)stages.size(), &fire, (float)gtol, 250));
     CHECK(c3d_set_option(ctx, "use_graph", use_graph));
     CHECK(c3d_init_replicas(ctx, models, seed, first_rep));
