@@ -1,4 +1,5 @@
-"""Convergence of the final minimisation (FIRE, the stand-in for the reference's 10 x 15000-step L-BFGS, deck :1790-1803):
+"""Convergence of the final minimisation (the stand-in for the reference's 10 x 15000-step L-BFGS, deck :1790-1803) — the stage as shipped
+(two-point step sizes, FIRE after 1000 steps; FINAL_MINIMISER=0 in the environment: FIRE throughout, rounds 1-4):
 largest RMS force component over 20 replicas against minimiser steps, for BASELINE configs 2 and 3 and a mid-size matrix.
     python tools/fire_convergence.py [cid ...]"""
 import os, sys
@@ -7,6 +8,7 @@ import numpy as np
 from chromosome3d_amd import Solver, default_model, default_schedule, pipeline
 from tests.util import load_if
 s = Solver(0)
+s.set_option("final_minimiser", int(os.environ.get("FINAL_MINIMISER", "1")))
 for cid in sys.argv[1:] or ["chr21_1mb", "chr4_1mb", "chr1_500kb"]:
     IF = load_if(cid)
     s.set_model(default_model()); pipeline.IF2dist_new(s, IF)
