@@ -193,6 +193,7 @@ struct c3d_ctx {
     long rank_prefetch_hits = 0;
     long k1_recomputed = 0, k1_patched = 0;   // K1: near-tie elements redone on the host in the reference's order / changed by it
     long graph_captures = 0, graph_launches = 0, step_launches = 0, resident_launches = 0, cluster_launches = 0;
+    bool last_two_point = false;           // the last multi-step launch was k_cluster_tp (its range held two-point minimiser steps)
     int last_path = 0;                     // 0 per-step, 2 k_cluster, 3 fp64 reference (what the last run_ops used)
     bool last_general = false;             // the last per-step launch took the general-form kernel (general tails, or an op without restraint weight)
 
@@ -509,6 +510,9 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     if (c->kernel_timing) { pl.t0 = c->kev0; pl.t1 = c->kev1; }
     pl.static_place = c->static_place ? (c->inject_misplaced ? 2 : 1) : 0;
     pl.xcd_base = c->xcd_base;
+    pl.two_point = false;
+    for (size_t k = 0; k < nops && !pl.two_point; ++k) pl.two_point = c->program[c->pc + k].p.kind >= 5;
+    c->last_two_point = pl.two_point;
     c->inject_misplaced = false;
     c->h_tmo[2] = 0;
     const auto h0 = std::chrono::steady_clock::now();
@@ -1485,7 +1489,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
     const c3d::DevModel m = dev_model(c);
     const char* gen = (general_tail(m) || c->last_general) ? "true" : "false";     // of the last op launched on the per-step path
     const char* rs1 = (!general_tail(m) && m.rs == 1.0f) ? "true" : "false";
-    if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster<%d, %d, %d, %d, %s>", m.noe_pot, c->cl_plan.rpw, m.npad / 256, m.wl, c->cl_plan.late_tiles ? "true" : "false");
+    if (c->last_path == 2) snprintf(buf, sizeof(buf), "c3d::k_cluster%s<%d, %d, %d, %d, %s>", c->last_two_point ? "_tp" : "", m.noe_pot, c->cl_plan.rpw, m.npad / 256, m.wl, c->cl_plan.late_tiles ? "true" : "false");
     else if (use_sym(c)) snprintf(buf, sizeof(buf), "c3d::k_pairs_sym<%d, %s, false>", m.noe_pot, rs1);
     else if (c->precision == 64) snprintf(buf, sizeof(buf), "c3d::k64_step<%d, %s>", m.noe_pot, general_tail(m) ? "true" : "false");
     else if (wide_step(c, m, general_tail(m) || c->last_general)) snprintf(buf, sizeof(buf), "c3d::k_step<4, false, 4, false, 16, true>");

@@ -64,15 +64,19 @@ __device__ unsigned long long g_pstamps[8];
 #define CSTAMP_C(k) do { } while (0)
 #endif
 
-template <int POT, int RPW, int NB, int WL, bool LATE>
-__global__ __launch_bounds__(kClMaxThreads) void k_cluster(
+// The kernel's body.  TWO: the launch's range holds steps of the two-point minimiser (kinds 5 / 6).  Their row update is compiled into a
+// kernel of its own, k_cluster_tp: with it in the loop the other kinds' steps measured 0.3-1 % longer (same box, A/B, round 5) although
+// they never run it — the lone H0 wave's path is that sensitive to what else the loop holds — so the launches of the hot and cool stages
+// keep the kernel they had.
+template <int POT, int RPW, int NB, int WL, bool LATE, bool TWO>
+__device__ __forceinline__ void cluster_body(
     // argument order: the first 16 dwords arrive in SGPRs with the wave (kernarg preload, Makefile), the rest after a ~0.7 us fetch —
     // what the placement and the first loads of the prologue need comes first
     // (14 dwords here: 16 user SGPRs less the kernarg pointer)
     const float* __restrict__ tgt, unsigned* __restrict__ claim, const StepRun* __restrict__ runs, const int P, const int CW, const int NH,
     const int static_place, const int nbeads, const int run0, const int skip0, const int nsteps,
     const unsigned tag_base, u32x4* __restrict__ rec, volatile unsigned* __restrict__ timeout, const unsigned expected,
-    const AnnealIO io, const DevModel m, const DevFire fp) {
+    const AnnealIO& io, const DevModel& m, const DevFire& fp) {
     constexpr int NPAD = 256 * NB;
     constexpr int MAXT = NPAD / 8;
     constexpr int KUMAX = NB > 2 ? 3 : 2;         // gather loads per thread: P * 2 RW <= threads * KUMAX
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
       if (run != run0) cur = runs[run];
       const DevStep p = cur.p;
       const int count = cur.count;
-      const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2 || p.kind == 5;
+      const bool needs_partials = p.kind == 0 || p.kind == 1 || p.kind == 2 || (TWO && p.kind == 5);
       for (int it = run == run0 ? skip0 : 0; it < count; ++it, ++s) {
 #ifdef C3D_STAMPS
         if (cstamper && s == 0) g_pstamps[7] = __builtin_amdgcn_s_memrealtime();
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
             }
         } else if constexpr (ROLE == 1) {
             // ---- replica sums of the previous step -> scalars of this one (only H0 needs them) -----------
-            if (p.kind != 2 && p.kind != 5) { st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0; }
+            if (p.kind != 2 && !(TWO && p.kind == 5)) { st.dt = fp.dt_start; st.alpha = fp.alpha_start; st.npos = 0; st.pad = 0; }
             float4 psum = make_float4(0, 0, 0, 0);
             if (needs_partials) {
                 if (late && !solo && s > 0) {
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                 psum.z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(psum.z)));
                 psum.w = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(psum.w)));
             }
-            sc = step_scalars(m, p, fp, psum, st);
+            sc = step_scalars<TWO>(m, p, fp, psum, st);
             // this row's position: read now, the barrier below is long
             if (lane < RW && hrow < NPAD) { hx0 = xs[hrow]; hy0 = ys[hrow]; hz0 = zs[hrow]; }
             CSTAMP(1);                              // H0: sums + scalars done
@@ -430,13 +434,17 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
                     xn = hx0; yn = hy0; zn = hz0;       // padding row (one-workgroup replicas write it back as it is)
                 }
             };
-            switch (p.kind) {
+            bool two_point_step = false;
+            if constexpr (TWO) {                            // (the two-point minimiser's kinds: k_cluster_tp only)
+                two_point_step = p.kind >= 5;
+                if (p.kind == 5) row_update(std::integral_constant<int, 5>{});
+                else if (p.kind == 6) row_update(std::integral_constant<int, 6>{});
+            }
+            if (!two_point_step) switch (p.kind) {
                 case 0: row_update(std::integral_constant<int, 0>{}); break;
                 case 1: row_update(std::integral_constant<int, 1>{}); break;
                 case 2: row_update(std::integral_constant<int, 2>{}); break;
                 case 3: row_update(std::integral_constant<int, 3>{}); break;
-                case 5: row_update(std::integral_constant<int, 5>{}); break;
-                case 6: row_update(std::integral_constant<int, 6>{}); break;
                 default: row_update(std::integral_constant<int, 4>{}); break;
             }
             // B3 (see the other roles below): the rows are out; what follows here — tile sums, their two units — is wanted by the
@@ -531,6 +539,20 @@ __global__ __launch_bounds__(kClMaxThreads) void k_cluster(
     else if (is_h0) role_loop(std::integral_constant<int, 1>{});
     else role_loop(std::integral_constant<int, 2>{});
 }
+
+#define C3D_CLUSTER_ARGS                                                                                                                  \
+    const float* __restrict__ tgt, unsigned* __restrict__ claim, const StepRun* __restrict__ runs, const int P, const int CW, const int NH, \
+    const int static_place, const int nbeads, const int run0, const int skip0, const int nsteps, const unsigned tag_base,                 \
+    u32x4* __restrict__ rec, volatile unsigned* __restrict__ timeout, const unsigned expected, const AnnealIO io, const DevModel m, const DevFire fp
+#define C3D_CLUSTER_PASS tgt, claim, runs, P, CW, NH, static_place, nbeads, run0, skip0, nsteps, tag_base, rec, timeout, expected, io, m, fp
+// MD and FIRE steps (every launch of the hot and cool stages, the regularisation, FIRE's part of the final stage)
+template <int POT, int RPW, int NB, int WL, bool LATE>
+__global__ __launch_bounds__(kClMaxThreads) void k_cluster(C3D_CLUSTER_ARGS) { cluster_body<POT, RPW, NB, WL, LATE, false>(C3D_CLUSTER_PASS); }
+// ranges that hold two-point minimiser steps (the first part of the final stage)
+template <int POT, int RPW, int NB, int WL, bool LATE>
+__global__ __launch_bounds__(kClMaxThreads) void k_cluster_tp(C3D_CLUSTER_ARGS) { cluster_body<POT, RPW, NB, WL, LATE, true>(C3D_CLUSTER_PASS); }
+#undef C3D_CLUSTER_ARGS
+#undef C3D_CLUSTER_PASS
 
 // Built as six translation units (Makefile): this file once with -DC3D_CLUSTER_SPLIT — planner, dispatch, k_tear16, no instantiation of
 // k_cluster — and once per device potential with -DC3D_CLUSTER_POT=0..4, each carrying that potential's geometries alone.  The 5 MB code
@@ -660,20 +682,28 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
                              hipStream_t s) {
     // per (instantiation, device): more dynamic LDS than the 64 KB a launch gets by default.  Contexts of several host
     // threads launch concurrently (c3d_batch): the flag is atomic, setting the attribute twice is harmless
-    static std::atomic<bool> attr_set[64];
+    static std::atomic<bool> attr_set[2][64];
     const int dev = pl.device & 63;
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, WL, LATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int tp = pl.two_point ? 1 : 0;         // the range holds two-point minimiser steps: the kernel that carries their row update
+    if (!attr_set[tp][dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(tp ? reinterpret_cast<const void*>(&k_cluster_tp<POT, RPW, NB, WL, LATE>) : reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, WL, LATE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev].store(true, std::memory_order_release);
+        attr_set[tp][dev].store(true, std::memory_order_release);
     }
     const int sp = (pl.static_place & 0xff) | ((pl.xcd_base & 0xff) << 8) | ((pl.xcd_count & 0xff) << 16);      // decoded at the kernel's top
-    if (pl.t0 && pl.t1)
-        hipExtLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, tgt, claim, runs,
-                              pl.parts, pl.cw, pl.helpers, sp, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);
-    else
-        hipLaunchKernelGGL((k_cluster<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, tgt, claim, runs, pl.parts, pl.cw, pl.helpers,
-                           sp, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);
+#define C3D_CL_LAUNCH(K)                                                                                                                              \
+    do {                                                                                                                                              \
+        if (pl.t0 && pl.t1)                                                                                                                           \
+            hipExtLaunchKernelGGL((K<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, pl.t0, pl.t1, 0, tgt, claim, runs,          \
+                                  pl.parts, pl.cw, pl.helpers, sp, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp); \
+        else                                                                                                                                          \
+            hipLaunchKernelGGL((K<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, tgt, claim, runs, pl.parts, pl.cw, pl.helpers, \
+                               sp, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);                \
+    } while (0)
+    if (tp) C3D_CL_LAUNCH(k_cluster_tp);
+    else C3D_CL_LAUNCH(k_cluster);
+#undef C3D_CL_LAUNCH
     return hipGetLastError();
 }
 template <int POT>

@@ -124,6 +124,7 @@ struct ClusterPlan {
     int rpw, cw, helpers, wgs_per_cu, parts, per_xcd, grid, threads, units, device;
     int static_place = 1;                         // slot = blockIdx / 8, checked against the XCC id (0: per-XCD atomic counters)
     int xcd_base = 0, xcd_count = 8;              // the launch lives on XCDs xcd_base .. xcd_base + xcd_count - 1 (replica r on XCD xcd_base + r % xcd_count): two
+    bool two_point = false;        // the launch's range holds two-point minimiser steps (kinds 5 / 6): k_cluster_tp
                                                   // contexts with disjoint sets anneal side by side (c3d_set_option "cluster_xcd_count" / "cluster_xcd_base")
     int late_tiles = 0;                           // tile sums fetched by H0 after the step has started instead of gating it (c3d_cluster.hip)
     unsigned expected = 0;                        // workgroups that must report completion: replicas x parts (the host may raise it: test hook)

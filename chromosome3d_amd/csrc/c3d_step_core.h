@@ -783,6 +783,8 @@ struct StepScalars {
 // psum: MD kinds 0/1 = (sum v^2, sum vx, sum vy, sum vz) of the previous half step;
 //       FIRE kind 2 = (v.F, F.F, v.v) of the previous evaluation; kind 3 (first step of a stage) = 0, fresh state
 //       two-point step size kind 5 = (s.y, F.F, y.y, s.s) of the previous evaluation; kind 6 (first step of a stage) = nothing, fresh state
+// TWO = false: a kernel that never runs the two-point minimiser's kinds (5 / 6) does not carry their branch (c3d_cluster.hip: k_cluster)
+template <bool TWO = true>
 __device__ __forceinline__ StepScalars step_scalars(const DevModel& m, const DevStep& p, const DevFire& fp, const float4 psum,
                                                     FireState& st) {
     StepScalars s;
@@ -800,7 +802,7 @@ __device__ __forceinline__ StepScalars step_scalars(const DevModel& m, const Dev
         // products that a subtraction follows (finish_row: v - v_cm): hidden from the instruction selector, so that "product, then difference"
         // is what every kernel computes whatever the backend would like to fuse under -ffp-contract=fast (see row_total)
         asm("" : "+v"(s.cmx), "+v"(s.cmy), "+v"(s.cmz));
-    } else if (p.kind == 5 || p.kind == 6) {
+    } else if (TWO && (p.kind == 5 || p.kind == 6)) {
         // two-point step size (Barzilai-Borwein) with the length one evaluation late (the CPU restatement: c3o_bb_step): lam = the length of the previous
         // move (to rebuild it from the force kept in the velocity slot), mix = the length of this one; st.dt / st.npos carry them on
         const int k = p.kind == 6 ? 0 : st.npos;

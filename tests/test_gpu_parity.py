@@ -381,12 +381,14 @@ def test_final_minimiser_option_and_the_stage_kinds(solver):
         solver.set_schedule(make_stages(sched), default_fire(), 1e-2, 250)
         solver.init_replicas(6, 82364, 0)
         solver.run()
-        out[name] = (solver.coords(), solver.energies(), solver.last_timing()[1])
+        out[name] = (solver.coords(), solver.energies(), solver.last_timing()[1], solver.step_kernel_name)
     solver.set_option("final_minimiser", 1)
     fire = out["two, option 1"]
     for name in ("five, option 0", "two, option 0"):
         assert np.array_equal(out[name][0], fire[0]) and out[name][2] == fire[2], name
     two_point = out["five, option 1"]
+    # the launches that hold two-point steps run the kernel that carries their row update; every other launch the one it always ran
+    assert two_point[3].startswith("c3d::k_cluster_tp<") and fire[3].startswith("c3d::k_cluster<"), (two_point[3], fire[3])
     assert not np.array_equal(two_point[0], fire[0]) and two_point[2] < fire[2], (two_point[2], fire[2])
     ea, eb = np.sort(two_point[1].sum(axis=1)), np.sort(fire[1].sum(axis=1))
     assert np.abs(ea - eb).max() <= 1e-6 * eb.max(), (ea, eb)
