@@ -193,6 +193,7 @@ struct c3d_ctx {
     long rank_prefetch_hits = 0;
     long k1_recomputed = 0, k1_patched = 0;   // K1: near-tie elements redone on the host in the reference's order / changed by it
     long graph_captures = 0, graph_launches = 0, step_launches = 0, resident_launches = 0, cluster_launches = 0;
+    bool has_two_point = false;            // the program holds two-point minimiser steps (run_ops splits ranges at their borders)
     bool last_two_point = false;           // the last multi-step launch was k_cluster_tp (its range held two-point minimiser steps)
     int last_path = 0;                     // 0 per-step, 2 k_cluster, 3 fp64 reference (what the last run_ops used)
     bool last_general = false;             // the last per-step launch took the general-form kernel (general tails, or an op without restraint weight)
@@ -336,6 +337,8 @@ void build_program(c3d_ctx* c) {
     c->pc = 0;
     c->zero_weight = false;
     for (const Op& op : c->program) c->zero_weight = c->zero_weight || op.p.w_rs == 0.0f;
+    c->has_two_point = false;
+    for (const Op& op : c->program) c->has_two_point = c->has_two_point || op.p.kind >= 5;
     drop_graphs(c);
     // run-length code of the whole program (a FIRE stage is 2 runs, the cool ramp 81) for the cluster kernel
     c->prog_runs.clear();
@@ -394,6 +397,29 @@ void group_range(const c3d_ctx* c, int g, int& base, int& count) {
 }
 int active_groups(const c3d_ctx* c) { return std::min(c->ngroups, std::max(c->nrep, 1)); }
 
+// Code objects load on the first use of one of their kernels, and several host threads doing that at once is what the runtime does not
+// survive reliably (eight contexts of one process starting together — c3d_batch --devices 4 --lanes 2 --map-devices-to 0 — crashed in it
+// once the multi-step unit held twice the kernels; one in thirty runs still did with that unit alone behind a mutex).  So every first touch
+// of a unit goes through load_unit(): once per (unit, device) in the process, one at a time (c3d::code_object_mutex, which the multi-step
+// kernels' hipFuncSetAttribute takes too), and whoever comes second waits for the first to be through.
+enum Unit { UNIT_CLUSTER = 0, UNIT_SCORE, UNIT_DEVICE, UNIT_EMBED, UNIT_F64, UNIT_SYM, UNIT_COUNT };
+static void load_unit(Unit u, int device) {
+    static std::once_flag once[UNIT_COUNT][64];
+    std::call_once(once[u][device & 63], [u] {
+        // (preload_cluster_unit takes the mutex itself)
+        if (u == UNIT_CLUSTER) { (void)c3d::preload_cluster_unit(); return; }
+        std::lock_guard<std::mutex> lk(c3d::code_object_mutex());
+        switch (u) {
+            case UNIT_SCORE: (void)c3d::preload_score_unit(); break;
+            case UNIT_DEVICE: (void)c3d::preload_device_unit(); break;
+            case UNIT_EMBED: (void)c3d::preload_embed_unit(); break;
+            case UNIT_F64: (void)c3d::preload_f64_unit(); break;
+            case UNIT_SYM: (void)c3d::preload_sym_unit(); break;
+            default: break;
+        }
+    });
+}
+
 bool use_sym(const c3d_ctx* c) {
     if (!c->d_sym_scratch) return false;
     return c->sym > 0;
@@ -407,6 +433,7 @@ void model_host64(const c3d_ctx* c, double (&mh)[15]) {
 }
 // fp64 target matrix from the resident integer tenths, in the encoding the current model's kernel expects (c3d_f64.hip pair64)
 int build_targets64(c3d_ctx* c) {
+    load_unit(UNIT_F64, c->device);
     double mh[15];
     model_host64(c, mh);
     hipError_t e = c3d::launch_targets64(dev_model(c), mh, c->model.min_sep, c->b64.t10, c->b64.T, c->stream);
@@ -484,7 +511,9 @@ void account_ops(c3d_ctx* c, size_t nops) {
     c->pc += nops;
 }
 
+
 int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
+    load_unit(UNIT_CLUSTER, c->device);
     if (c->prog_dirty) {
         if (c->prog_runs.size() > c->prog_cap) {
             if (c->d_prog) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_prog); c->d_prog = nullptr; }
@@ -561,13 +590,16 @@ int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w);
 
 // A stage without restraint weight (w_all = 0: the clamp form divides by it) takes the general kernels; the ops around it keep the
 // multi-step launches: the range is split where the weight changes between zero and non-zero.
+// The range is also split where two-point minimiser steps (kinds 5 / 6) begin or end: a multi-step launch that holds any of them runs
+// k_cluster_tp, 2.5 % slower per step than k_cluster (c3d_cluster.hip) — the MD stages before a final stage of kind 5 keep their kernel
+// also when a caller asks for the whole schedule in one c3d_run_steps.
 int run_ops(c3d_ctx* c, size_t nops) {
-    if (!c->zero_weight || c->precision == 64) return run_ops_segment(c, nops, false);
+    if ((!c->zero_weight && !c->has_two_point) || c->precision == 64) return run_ops_segment(c, nops, false);
     const size_t end = c->pc + nops;
     while (c->pc < end) {
-        const bool z = c->program[c->pc].p.w_rs == 0.0f;
+        const bool z = c->program[c->pc].p.w_rs == 0.0f, tp = c->program[c->pc].p.kind >= 5;
         size_t k = 1;
-        while (c->pc + k < end && (c->program[c->pc + k].p.w_rs == 0.0f) == z) ++k;
+        while (c->pc + k < end && (c->program[c->pc + k].p.w_rs == 0.0f) == z && (c->program[c->pc + k].p.kind >= 5) == tp) ++k;
         const int rc = run_ops_segment(c, k, z);
         if (rc) return rc;
     }
@@ -587,6 +619,9 @@ int ensure_group_streams(c3d_ctx* c, int G) {
 
 int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w) {
     if (nops == 0) return C3D_OK;
+    load_unit(UNIT_DEVICE, c->device);
+    if (c->precision == 64) load_unit(UNIT_F64, c->device);
+    else if (use_sym(c)) load_unit(UNIT_SYM, c->device);
     if (c->preload.joinable()) c->preload.join();      // c3d_create's helper: the kernels it loads are wanted now
     if (c->precision == 64 || zero_w) { }                                           // fp64: the per-step path below (k64_step), never the cluster kernel
     else if (c->resident_skip > 0 && c->resident < 1) --c->resident_skip;     // cooling off after an abandoned launch
@@ -742,6 +777,7 @@ int partials_finite(c3d_ctx* c, bool* ok) {
 
 // fp64 state <- the fp32 coordinates of the current parity (start structures, c3d_set_coords, the DG embedding); velocities zero
 int import64(c3d_ctx* c) {
+    load_unit(UNIT_F64, c->device);
     hipError_t e = c3d::launch_import64(dev_model(c), c->buf.X[c->parity], c->b64, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 import: ") + hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -815,6 +851,7 @@ extern "C" int c3d_default_schedule(c3d_stage* st, int cap, int min_steps) {
 }
 
 static std::atomic<int> g_preload{1};
+
 extern "C" int c3d_set_process_option(const char* key, double value) {
     if (!key) return fail(C3D_ERR_INVALID, "c3d_set_process_option: null key");
     if (!strcmp(key, "preload")) { g_preload.store(value != 0); return C3D_OK; }
@@ -868,9 +905,9 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     if (g_preload.load() && !(preloaded.fetch_or(bit) & bit))
         c->preload = std::thread([device] {
             if (hipSetDevice(device) != hipSuccess) return;
-            (void)c3d::preload_cluster_unit();     // the largest first; the caller's own first launch (K1) loads c3d_device's meanwhile
-            (void)c3d::preload_score_unit();
-            (void)c3d::preload_device_unit();
+            load_unit(UNIT_CLUSTER, device);       // the largest first; the caller's own first launch (K1) asks for c3d_device's and takes its turn
+            load_unit(UNIT_SCORE, device);
+            load_unit(UNIT_DEVICE, device);
         });
     *out = c;
     return C3D_OK;
@@ -1030,6 +1067,7 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     if (!c || !IF || n < 2) return fail(C3D_ERR_INVALID, "c3d_set_if_matrix: bad arguments");
     if (n > kMaxBeads) return fail(C3D_ERR_INVALID, "c3d_set_if_matrix: more than 5120 beads are not supported by this build");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     free_replica_buffers(c);
     set_dims(c, n);
     const size_t nn = (size_t)n * n;
@@ -1118,6 +1156,7 @@ extern "C" int c3d_set_restraints(c3d_ctx* c, int n, int R, const int32_t* ri, c
     if (!c || n < 2 || R < 0 || (R > 0 && (!ri || !rj || !rt10))) return fail(C3D_ERR_INVALID, "c3d_set_restraints: bad arguments");
     if (n > kMaxBeads) return fail(C3D_ERR_INVALID, "c3d_set_restraints: more than 5120 beads are not supported by this build");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     free_replica_buffers(c);
     set_dims(c, n);
     std::vector<float> enc((size_t)n * c->npad);
@@ -1152,6 +1191,7 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
     if (!c || nrep < 1) return fail(C3D_ERR_INVALID, "c3d_init_replicas: bad arguments");
     if (!c->have_targets) return fail(C3D_ERR_INVALID, "c3d_init_replicas: set the IF matrix / restraints first");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     if (c->have_replicas && nrep != c->nrep) free_replica_buffers(c);
     c->nrep = nrep; c->seed = seed; c->first_rep = first_replica;
     const size_t nf = c->rep_floats * nrep;
@@ -1297,6 +1337,8 @@ extern "C" int c3d_embed_replicas(c3d_ctx* c, int iters) {
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_embed_replicas: call c3d_init_replicas first");
     if ((size_t)9 * c->n + 16 > 160 * 1024 / sizeof(float)) return fail(C3D_ERR_INVALID, "c3d_embed_replicas: too many beads for the embedding kernel");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
+    load_unit(UNIT_EMBED, c->device);
     const int n = c->n, nrep = c->nrep;
     const size_t nn = (size_t)n * n;
     DevTmp<float> U, L, D2, v0;
@@ -1326,6 +1368,7 @@ extern "C" int c3d_set_coords(c3d_ctx* c, const float* xyz) {
     if (!c || !xyz) return fail(C3D_ERR_INVALID, "c3d_set_coords: null argument");
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_set_coords: call c3d_init_replicas first");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     std::vector<float> soa;
     pack(c, xyz, soa, true);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1342,11 +1385,13 @@ static int get_soa(c3d_ctx* c, const float* dev, float* aos) {
 extern "C" int c3d_get_coords(c3d_ctx* c, float* xyz) {
     if (!c || !xyz || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_get_coords: bad state");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     return get_soa(c, c->buf.X[c->parity], xyz);
 }
 extern "C" int c3d_get_velocities(c3d_ctx* c, float* v) {
     if (!c || !v || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_get_velocities: bad state");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     return get_soa(c, c->buf.V[c->parity], v);
 }
 
@@ -1362,6 +1407,7 @@ extern "C" int c3d_run_steps(c3d_ctx* c, long nsteps, long* done) {
     if (!c || nsteps < 0) return fail(C3D_ERR_INVALID, "c3d_run_steps: bad arguments");
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_run_steps: call c3d_init_replicas first");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     // number of program ops that contain exactly nsteps counted steps (or the rest of the program)
     size_t nops = 0;
     long counted = 0;
@@ -1382,6 +1428,7 @@ extern "C" int c3d_run_steps(c3d_ctx* c, long nsteps, long* done) {
 extern "C" int c3d_centre(c3d_ctx* c) {
     if (!c || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_centre: bad state");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     hipError_t e = c3d::launch_centre(dev_model(c), c->buf, c->parity, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("centre launch: ") + hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1392,6 +1439,7 @@ extern "C" int c3d_run(c3d_ctx* c) {
     if (!c) return fail(C3D_ERR_INVALID, "c3d_run: null context");
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_run: call c3d_init_replicas first");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     int rc = begin_timing(c);
     if (rc) return rc;
     const int last_stage = (int)c->stages.size() - 1;
@@ -1500,6 +1548,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
 extern "C" int c3d_eval(c3d_ctx* c, float w_all, float w_vdw, float repel_s, float* F, double* e) {
     if (!c || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_eval: bad state");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     const c3d::DevModel m = dev_model(c);
     const c3d::DevStep p = dev_step(c, 3, 0.0f, w_all, w_vdw, repel_s, 0.0f);
     if (F) {
@@ -1533,6 +1582,8 @@ extern "C" int c3d_score_replicas(c3d_ctx* c, const double* IF, int range, int32
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_score_replicas: call c3d_init_replicas first");
     if (rho && !IF) return fail(C3D_ERR_INVALID, "c3d_score_replicas: the Spearman coefficient needs the IF matrix");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
+    load_unit(UNIT_SCORE, c->device);
     const int n = c->n, nrep = c->nrep;
     const unsigned nbins = 1u << 18;      // distances up to 262 A in thousandths
     std::vector<double> rankA;
@@ -1614,6 +1665,7 @@ extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
 extern "C" int c3d_debug_tear16(c3d_ctx* c, int iterations, unsigned long long* unit_reads, unsigned long long* torn, unsigned long long* fresh) {
     if (!c || iterations < 1 || iterations > (1 << 24)) return fail(C3D_ERR_INVALID, "c3d_debug_tear16: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
+    load_unit(UNIT_DEVICE, c->device);
     DevTmp<unsigned char> buf;
     DevTmp<unsigned> stop;
     DevTmp<unsigned long long> stats;

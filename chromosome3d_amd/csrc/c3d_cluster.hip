@@ -686,6 +686,7 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
     const int dev = pl.device & 63;
     const int tp = pl.two_point ? 1 : 0;         // the range holds two-point minimiser steps: the kernel that carries their row update
     if (!attr_set[tp][dev].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lk(code_object_mutex());
         hipError_t e = hipFuncSetAttribute(tp ? reinterpret_cast<const void*>(&k_cluster_tp<POT, RPW, NB, WL, LATE>) : reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, WL, LATE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -780,8 +781,13 @@ AnnealIO anneal_io(const DevBuffers& b, int parity) {
     return io;
 }
 
+std::mutex& code_object_mutex() {
+    static std::mutex mu;
+    return mu;
+}
 // the unit of the shipped potential (device potential 4): what a default job launches
 hipError_t preload_cluster_unit() {
+    std::lock_guard<std::mutex> lk(code_object_mutex());
 #if defined(C3D_CLUSTER_SPLIT)
     return preload_cluster_pot4();
 #else

@@ -336,4 +336,9 @@ hipError_t launch_dg_embed(const float* tgt, int n, int npad, int nrep, float b0
     return hipGetLastError();
 }
 
+hipError_t preload_embed_unit() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_dg_clamp));
+}
+
 }  // namespace c3d

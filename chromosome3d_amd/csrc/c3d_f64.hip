@@ -534,4 +534,9 @@ hipError_t launch_export64(const DevModel& d, const Buffers64& b, int parity, fl
     return hipGetLastError();
 }
 
+hipError_t preload_f64_unit() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k64_import));
+}
+
 }  // namespace c3d

@@ -1,6 +1,7 @@
 // c3d_internal.h — shared between the HIP kernels (c3d_device.hip) and the C-ABI host (c3d_api.cpp).
 // Not part of the public boundary (that is include/c3d.h).
 #pragma once
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -140,9 +141,16 @@ hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPla
 // Code objects are loaded on the first use of one of their kernels, one object per translation unit (K1's 2-3 ms, the shipped potential's
 // multi-step kernels 3 ms, scoring 0.3 ms).  These touch one kernel of their unit so that c3d_create can have them loaded on a helper thread
 // while the caller parses its input.
+// (first touches of the multi-step kernels' code objects — the helper thread's and every context's hipFuncSetAttribute before its first launch
+//  of an instantiation — go one at a time: eight contexts of one process starting at once, c3d_batch --devices 4 --lanes 2 --map-devices-to 0,
+//  crashed in the runtime's lazy loading of the unit once it held twice the kernels, round 5)
+std::mutex& code_object_mutex();
 hipError_t preload_device_unit();
 hipError_t preload_cluster_unit();
 hipError_t preload_score_unit();
+hipError_t preload_embed_unit();
+hipError_t preload_f64_unit();
+hipError_t preload_sym_unit();
 hipError_t launch_tear16(int num_cus, void* buf, unsigned* stop, unsigned long long* stats, int iters, hipStream_t s);
 // symmetric-tile step for large N (c3d_sym.hip): every pair once.  tiles = sym_tile_list() uploaded, scratch =
 // sym_scratch_floats() floats of device memory (row-side and column-side partial forces of one step).

@@ -250,4 +250,9 @@ hipError_t launch_step_sym(const DevModel& m, const DevStep& p, const DevFire& f
 #undef C3D_SYM
 }
 
+hipError_t preload_sym_unit() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_update_sym<0>));
+}
+
 }  // namespace c3d
