@@ -257,6 +257,12 @@ def test_batch_executor_per_device_lists_and_threads_rehearsed_on_one_gpu(built,
         for k in range(1, 6):
             assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["four"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
             assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["paired"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
+    # eight contexts of one process starting at once, again and again: the runtime's lazy loading of code objects is not safe against that,
+    # libc3d takes the first touch of every unit one at a time (c3d_api.cpp load_unit; 2 of 2 such starts crashed before, round 5)
+    for rep in range(6):
+        p = subprocess.run([exe] + mats + ["--out", str(tmp_path / f"again{rep}"), "-m", "6", "--devices", "4", "--lanes", "2", "--map-devices-to", "0"],
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "0 failed" in p.stdout, (rep, p.returncode, p.stderr[-300:])
     # --pair 1 (default), three lanes: the small chromosomes annealed on halves of the device, --pair 0: nobody did
     assert " XCDs " in runs["paired"][1] and " XCDs " not in runs["one"][1]
     bad = subprocess.run([exe] + mats[:1] + ["--out", str(tmp_path / "x"), "--map-devices-to", "7"], capture_output=True, text=True)
