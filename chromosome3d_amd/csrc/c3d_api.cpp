@@ -173,6 +173,7 @@ struct c3d_ctx {
     size_t d_score_bytes = 0;
     size_t h_stage_bytes = 0;
     std::thread preload;                   // loads the code objects of the job's kernels while the caller is busy on the host (c3d_create)
+    std::thread tp_loader;                 // loads the two-point twin of the multi-step unit beside the process's first anneal (kick_two_point_unit)
     // The IF side of the Spearman coefficient (average ranks of the matrix's ordered pairs: a radix sort of up to 2 x 10^5 records, 5 ms at
     // N = 455) depends on the INPUT alone: c3d_set_if_matrix starts it on a helper thread over a copy of the matrix, and c3d_score_replicas
     // — which comes after the anneal — takes the result when its IF argument holds the same numbers (memcmp), else computes as before.
@@ -402,12 +403,26 @@ int active_groups(const c3d_ctx* c) { return std::min(c->ngroups, std::max(c->nr
 // once the multi-step unit held twice the kernels; one in thirty runs still did with that unit alone behind a mutex).  So every first touch
 // of a unit goes through load_unit(): once per (unit, device) in the process, one at a time (c3d::code_object_mutex, which the multi-step
 // kernels' hipFuncSetAttribute takes too), and whoever comes second waits for the first to be through.
-enum Unit { UNIT_CLUSTER = 0, UNIT_SCORE, UNIT_DEVICE, UNIT_EMBED, UNIT_F64, UNIT_SYM, UNIT_COUNT };
+enum Unit { UNIT_CLUSTER = 0, UNIT_CLUSTER_TP, UNIT_SCORE, UNIT_DEVICE, UNIT_EMBED, UNIT_F64, UNIT_SYM, UNIT_COUNT };
+static void load_unit(Unit u, int device);
+// the two-point twin of the multi-step unit, loaded beside the first anneal's MD stages (the host thread waits on the device then): once per
+// process and device, on a thread the context owns — load_unit makes whoever needs the unit first wait for it
+static void kick_two_point_unit(c3d_ctx* c) {
+    static std::atomic<unsigned long long> kicked{0};
+    const int device = c->device;
+    const unsigned long long bit = 1ull << (device & 63);
+    if (!c->has_two_point || (kicked.fetch_or(bit) & bit)) return;
+    c->tp_loader = std::thread([device] {          // joined by c3d_destroy
+        if (hipSetDevice(device) != hipSuccess) return;
+        load_unit(UNIT_CLUSTER_TP, device);
+    });
+}
 static void load_unit(Unit u, int device) {
     static std::once_flag once[UNIT_COUNT][64];
     std::call_once(once[u][device & 63], [u] {
-        // (preload_cluster_unit takes the mutex itself)
+        // (the multi-step units' preload functions take the mutex themselves)
         if (u == UNIT_CLUSTER) { (void)c3d::preload_cluster_unit(); return; }
+        if (u == UNIT_CLUSTER_TP) { (void)c3d::preload_cluster_tp_unit(); return; }
         std::lock_guard<std::mutex> lk(c3d::code_object_mutex());
         switch (u) {
             case UNIT_SCORE: (void)c3d::preload_score_unit(); break;
@@ -542,6 +557,7 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     pl.two_point = false;
     for (size_t k = 0; k < nops && !pl.two_point; ++k) pl.two_point = c->program[c->pc + k].p.kind >= 5;
     c->last_two_point = pl.two_point;
+    if (pl.two_point) load_unit(UNIT_CLUSTER_TP, c->device);
     c->inject_misplaced = false;
     c->h_tmo[2] = 0;
     const auto h0 = std::chrono::steady_clock::now();
@@ -905,7 +921,11 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
     if (g_preload.load() && !(preloaded.fetch_or(bit) & bit))
         c->preload = std::thread([device] {
             if (hipSetDevice(device) != hipSuccess) return;
-            load_unit(UNIT_CLUSTER, device);       // the largest first; the caller's own first launch (K1) asks for c3d_device's and takes its turn
+            // one at a time (load_unit).  The multi-step kernels' unit first (3 ms, the largest of the three): it is through before the caller
+            // has parsed its matrix and asks for K1's unit — which it then finds loaded, or loads itself, or waits for while this thread
+            // does.  The twin unit of the final stage's two-point part is NOT loaded here: every HIP call of the caller's K1 phase would
+            // queue behind those 3 ms inside the runtime; the first c3d_run of the process starts that load beside its MD stages (below).
+            load_unit(UNIT_CLUSTER, device);
             load_unit(UNIT_SCORE, device);
             load_unit(UNIT_DEVICE, device);
         });
@@ -916,6 +936,7 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
 extern "C" void c3d_destroy(c3d_ctx* c) {
     if (!c) return;
     if (c->preload.joinable()) c->preload.join();
+    if (c->tp_loader.joinable()) c->tp_loader.join();
     c->ifr.join();
     hipSetDevice(c->device);
     for (int g = 0; g < c3d_ctx::kMaxGroups; ++g) if (c->gstream[g]) hipStreamSynchronize(c->gstream[g]);
@@ -1149,6 +1170,8 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     c->R = R;
     c->have_targets = true;
     build_program(c);
+    // K1 is through; callers that write the front-half files next (8-10 ms of host work, no HIP call) hide the twin unit's load behind them
+    kick_two_point_unit(c);
     return C3D_OK;
 }
 
@@ -1417,6 +1440,7 @@ extern "C" int c3d_run_steps(c3d_ctx* c, long nsteps, long* done) {
     }
     int rc = begin_timing(c);
     if (rc) return rc;
+    kick_two_point_unit(c);
     rc = run_ops(c, nops);
     if (rc) return rc;
     rc = end_timing(c);
@@ -1450,6 +1474,7 @@ extern "C" int c3d_run(c3d_ctx* c) {
         nfixed = 0;
         while (c->pc + nfixed < c->program.size() && c->program[c->pc + nfixed].stage != last_stage) ++nfixed;
     }
+    kick_two_point_unit(c);
     rc = run_ops(c, nfixed);
     if (rc) return rc;
     if (early) {

@@ -682,13 +682,26 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
                              hipStream_t s) {
     // per (instantiation, device): more dynamic LDS than the 64 KB a launch gets by default.  Contexts of several host
     // threads launch concurrently (c3d_batch): the flag is atomic, setting the attribute twice is harmless
+    // which of the two kernels this translation unit holds: a unit built with -DC3D_CLUSTER_TP carries k_cluster_tp (ranges that hold
+    // two-point minimiser steps) and nothing else, the others k_cluster alone — a job's first launches load the code object they need
+    // (1.7 MB for the shipped potential, 3 ms), the twin's is loaded by c3d_create's helper afterwards or at the final stage's first launch;
+    // the single-unit build (neither split macro) holds both
+#if defined(C3D_CLUSTER_TP)
+    constexpr bool kHasLean = false, kHasTp = true;
+#elif defined(C3D_CLUSTER_POT)
+    constexpr bool kHasLean = true, kHasTp = false;
+#else
+    constexpr bool kHasLean = true, kHasTp = true;
+#endif
     static std::atomic<bool> attr_set[2][64];
     const int dev = pl.device & 63;
     const int tp = pl.two_point ? 1 : 0;         // the range holds two-point minimiser steps: the kernel that carries their row update
+    if ((tp && !kHasTp) || (!tp && !kHasLean)) return hipErrorInvalidValue;
     if (!attr_set[tp][dev].load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lk(code_object_mutex());
-        hipError_t e = hipFuncSetAttribute(tp ? reinterpret_cast<const void*>(&k_cluster_tp<POT, RPW, NB, WL, LATE>) : reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, WL, LATE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipSuccess;
+        if constexpr (kHasTp) { if (tp) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_tp<POT, RPW, NB, WL, LATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        if constexpr (kHasLean) { if (!tp) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, WL, LATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         if (e != hipSuccess) return e;
         attr_set[tp][dev].store(true, std::memory_order_release);
     }
@@ -702,8 +715,8 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
             hipLaunchKernelGGL((K<POT, RPW, NB, WL, LATE>), dim3(pl.grid), dim3(pl.threads), pl.lds, s, tgt, claim, runs, pl.parts, pl.cw, pl.helpers, \
                                sp, m.n, run0, skip0, nsteps, tag_base, reinterpret_cast<u32x4*>(rec), timeout, pl.expected, io, m, fp);                \
     } while (0)
-    if (tp) C3D_CL_LAUNCH(k_cluster_tp);
-    else C3D_CL_LAUNCH(k_cluster);
+    if constexpr (kHasTp) { if (tp) C3D_CL_LAUNCH(k_cluster_tp); }
+    if constexpr (kHasLean) { if (!tp) C3D_CL_LAUNCH(k_cluster); }
 #undef C3D_CL_LAUNCH
     return hipGetLastError();
 }
@@ -740,7 +753,18 @@ static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const Clust
 
 #define C3D_CL_CAT2(a, b) a##b
 #define C3D_CL_CAT(a, b) C3D_CL_CAT2(a, b)
-#if defined(C3D_CLUSTER_POT)
+#if defined(C3D_CLUSTER_POT) && defined(C3D_CLUSTER_TP)
+// one potential's unit of k_cluster_tp
+hipError_t C3D_CL_CAT(launch_cluster_tp_pot, C3D_CLUSTER_POT)(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
+                          const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
+                          hipStream_t s) {
+    return cluster_geom<C3D_CLUSTER_POT>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
+}
+hipError_t C3D_CL_CAT(preload_cluster_tp_pot, C3D_CLUSTER_POT)() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_cluster_tp<C3D_CLUSTER_POT, 2, 2, 4, false>));
+}
+#elif defined(C3D_CLUSTER_POT)
 // one potential's unit: its dispatch and one of its kernels to touch (preload)
 hipError_t C3D_CL_CAT(launch_cluster_pot, C3D_CLUSTER_POT)(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
@@ -756,7 +780,10 @@ hipError_t C3D_CL_CAT(preload_cluster_pot, C3D_CLUSTER_POT)() {
 #define C3D_CL_DECL(P) hipError_t launch_cluster_pot##P(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec, const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim, hipStream_t s); hipError_t preload_cluster_pot##P();
 C3D_CL_DECL(0) C3D_CL_DECL(1) C3D_CL_DECL(2) C3D_CL_DECL(3) C3D_CL_DECL(4)
 #undef C3D_CL_DECL
-#define C3D_CL_POT(P) launch_cluster_pot##P(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s)
+#define C3D_CL_DECL(P) hipError_t launch_cluster_tp_pot##P(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec, const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim, hipStream_t s); hipError_t preload_cluster_tp_pot##P();
+C3D_CL_DECL(0) C3D_CL_DECL(1) C3D_CL_DECL(2) C3D_CL_DECL(3) C3D_CL_DECL(4)
+#undef C3D_CL_DECL
+#define C3D_CL_POT(P) (pl.two_point ? launch_cluster_tp_pot##P(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s) : launch_cluster_pot##P(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s))
 #else
 #define C3D_CL_POT(P) cluster_geom<P>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s)
 #endif
@@ -793,6 +820,15 @@ hipError_t preload_cluster_unit() {
 #else
     hipFuncAttributes a;
     return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_tear16));
+#endif
+}
+// the twin unit of the shipped potential (k_cluster_tp: the final stage's two-point part)
+hipError_t preload_cluster_tp_unit() {
+    std::lock_guard<std::mutex> lk(code_object_mutex());
+#if defined(C3D_CLUSTER_SPLIT)
+    return preload_cluster_tp_pot4();
+#else
+    return hipSuccess;
 #endif
 }
 #endif  // C3D_CLUSTER_POT

@@ -147,6 +147,7 @@ hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPla
 std::mutex& code_object_mutex();
 hipError_t preload_device_unit();
 hipError_t preload_cluster_unit();
+hipError_t preload_cluster_tp_unit();
 hipError_t preload_score_unit();
 hipError_t preload_embed_unit();
 hipError_t preload_f64_unit();
