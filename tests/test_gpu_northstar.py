@@ -15,7 +15,7 @@ Which of our 20 replicas to compare: the bundled model of a chromosome is ONE of
 names carry ranks 1..10 (chr22_1mb_rank08, chr4_1mb_rank10, ...), never 11..20: it was picked among the ten lowest-energy models, by all
 appearance for its Spearman (spearman_IF_pdb.pl:73-76 prints the models sorted by it; order statistics: test below).  THE GATE is the
 literal north star:
-  * best-ENERGY replica: 43 of 45 within +-0.01 (8 seeds: 43 seven times, 42 once: profiles/r04_seed_robustness_all45.md); the two outside
+  * best-ENERGY replica: 43 of 45 within +-0.01 (8 seeds, final stage as shipped since round 5: profiles/r05_seed_robustness_all45.md; round 4: 43 seven times, 42 once, r04_seed_robustness_all45.md); the two outside
     are named below, STRICT xfails with hard bounds — on both our energy prefers another fold than the bundled one (by 0.75 % of E_noe on
     chr7_1mb, 5 % on chr22_1mb).  Round 5 asked the reference's own energy ranks (the rankNN of the file names): relaxed under our energy the
     bundled chr22_1mb (file rank 8) is 19th of our 20, chr7_1mb (rank 2) 11th — the model gap is real, not an artefact of which replica is
