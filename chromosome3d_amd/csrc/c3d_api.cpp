@@ -18,6 +18,8 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -172,8 +174,6 @@ struct c3d_ctx {
     void* d_score = nullptr;               // c3d_score_replicas' device scratch (ranks, rounded coordinates, sums, histograms), grown on demand
     size_t d_score_bytes = 0;
     size_t h_stage_bytes = 0;
-    std::thread preload;                   // loads the code objects of the job's kernels while the caller is busy on the host (c3d_create)
-    std::thread tp_loader;                 // loads the two-point twin of the multi-step unit beside the process's first anneal (kick_two_point_unit)
     // The IF side of the Spearman coefficient (average ranks of the matrix's ordered pairs: a radix sort of up to 2 x 10^5 records, 5 ms at
     // N = 455) depends on the INPUT alone: c3d_set_if_matrix starts it on a helper thread over a copy of the matrix, and c3d_score_replicas
     // — which comes after the anneal — takes the result when its IF argument holds the same numbers (memcmp), else computes as before.
@@ -185,6 +185,12 @@ struct c3d_ctx {
         int n = 0, range = 0;
         bool valid = false;
         void join() { if (worker.joinable()) worker.join(); }
+        void release() {                   // the worker's copies go with the matrix they belong to
+            join();
+            valid = false;
+            std::vector<double>().swap(matrix);
+            std::vector<double>().swap(rank);
+        }
     } ifr;
     int bb_steps = 1000;                   // option final_minimiser_steps: two-point steps before FIRE takes the stage over
     bool final_bb = true;                  // option final_minimiser: 1 = stages of kind 5 start with the two-point step-size minimiser, 0 = they are FIRE stages
@@ -398,42 +404,105 @@ void group_range(const c3d_ctx* c, int g, int& base, int& count) {
 }
 int active_groups(const c3d_ctx* c) { return std::min(c->ngroups, std::max(c->nrep, 1)); }
 
-// Code objects load on the first use of one of their kernels, and several host threads doing that at once is what the runtime does not
-// survive reliably (eight contexts of one process starting together — c3d_batch --devices 4 --lanes 2 --map-devices-to 0 — crashed in it
-// once the multi-step unit held twice the kernels; one in thirty runs still did with that unit alone behind a mutex).  So every first touch
-// of a unit goes through load_unit(): once per (unit, device) in the process, one at a time (c3d::code_object_mutex, which the multi-step
-// kernels' hipFuncSetAttribute takes too), and whoever comes second waits for the first to be through.
-enum Unit { UNIT_CLUSTER = 0, UNIT_CLUSTER_TP, UNIT_SCORE, UNIT_DEVICE, UNIT_EMBED, UNIT_F64, UNIT_SYM, UNIT_COUNT };
-static void load_unit(Unit u, int device);
-// the two-point twin of the multi-step unit, loaded beside the first anneal's MD stages (the host thread waits on the device then): once per
-// process and device, on a thread the context owns — load_unit makes whoever needs the unit first wait for it
-static void kick_two_point_unit(c3d_ctx* c) {
-    static std::atomic<unsigned long long> kicked{0};
-    const int device = c->device;
-    const unsigned long long bit = 1ull << (device & 63);
-    if (!c->has_two_point || (kicked.fetch_or(bit) & bit)) return;
-    c->tp_loader = std::thread([device] {          // joined by c3d_destroy
-        if (hipSetDevice(device) != hipSuccess) return;
-        load_unit(UNIT_CLUSTER_TP, device);
-    });
+// ---- code objects ---------------------------------------------------------------------------------------------------------------
+// The HIP runtime loads a code object (one per translation unit with kernels: sixteen in this library) at the first use of one of its
+// kernels.  Round 5 left that to the runtime and to helper threads, and eight contexts of one process starting together — c3d_batch
+// --devices 4 --lanes 2 --map-devices-to 0 — ended in a DEVICE exception once (rc -13: the runtime's GPU-core-dump helper does not
+// exist on the box, the process died on its pipe before the runtime could say which exception; DESIGN.md section 6 "code objects").
+// Since round 6 nothing is lazy and nothing is concurrent:
+//   * a unit is loaded by ensure_units() alone — the calling thread, one unit at a time, g_units.rw held EXCLUSIVELY;
+//   * every public entry that issues device work (kernels, copies, fills) holds g_units.rw SHARED for its whole duration (struct Entry)
+//     and names the units it can need before it takes it: a unit is never loaded while any thread of the process can launch;
+//   * c3d_create loads what a default job runs (per-step + K1 unit, both multi-step units of the shipped potential, scoring) before it
+//     returns — ~9 ms once per process and device (c3d_set_process_option "preload": 2 = all sixteen, 0 = each at the first entry that
+//     needs it); the multi-step and embedding units also get their dynamic-LDS allowance there (hipFuncSetAttribute per instantiation:
+//     state of the runtime, so it belongs under the same lock), and a launch changes no runtime state afterwards;
+//   * a load that fails is reported (C3D_ERR_HIP) and not remembered as done.
+// No helper thread of the library touches the HIP runtime any more (the IF-rank worker is host arithmetic only).
+enum Unit : unsigned {
+    UNIT_DEVICE = 0, UNIT_SCORE, UNIT_CLUSTER_BASE, UNIT_EMBED, UNIT_F64, UNIT_SYM,
+    UNIT_CLUSTER_P0, UNIT_CLUSTER_TP0 = UNIT_CLUSTER_P0 + 5, UNIT_COUNT = UNIT_CLUSTER_TP0 + 5
+};
+constexpr unsigned unit_bit(unsigned u) { return 1u << u; }
+constexpr unsigned kUnitsDefault = unit_bit(UNIT_DEVICE) | unit_bit(UNIT_SCORE) | unit_bit(UNIT_CLUSTER_P0 + 4) | unit_bit(UNIT_CLUSTER_TP0 + 4);
+constexpr unsigned kUnitsAll = (1u << UNIT_COUNT) - 1u;
+constexpr int kMaxDevices = 64;
+struct Units {
+    std::shared_mutex rw;
+    std::atomic<unsigned> loaded[kMaxDevices];     // bit u: unit u is loaded (and prepared) on that device
+    std::atomic<long> loads{0};                    // units loaded by this process (stat "units_loaded": a test reads it)
+    Units() { for (auto& a : loaded) a.store(0); }
+};
+Units g_units;
+thread_local int t_entry_depth = 0;                // public entries call one another (c3d_rank -> c3d_get_energies -> c3d_eval): the outermost one locks
+
+const char* unit_name(unsigned u) {
+    static const char* const names[] = {"per-step + K1", "scoring", "multi-step planner", "embedding", "fp64", "symmetric tiles"};
+    if (u < UNIT_CLUSTER_P0) return names[u];
+    return u < UNIT_CLUSTER_TP0 ? "multi-step (k_cluster)" : "multi-step (k_cluster_tp)";
 }
-static void load_unit(Unit u, int device) {
-    static std::once_flag once[UNIT_COUNT][64];
-    std::call_once(once[u][device & 63], [u] {
-        // (the multi-step units' preload functions take the mutex themselves)
-        if (u == UNIT_CLUSTER) { (void)c3d::preload_cluster_unit(); return; }
-        if (u == UNIT_CLUSTER_TP) { (void)c3d::preload_cluster_tp_unit(); return; }
-        std::lock_guard<std::mutex> lk(c3d::code_object_mutex());
-        switch (u) {
-            case UNIT_SCORE: (void)c3d::preload_score_unit(); break;
-            case UNIT_DEVICE: (void)c3d::preload_device_unit(); break;
-            case UNIT_EMBED: (void)c3d::preload_embed_unit(); break;
-            case UNIT_F64: (void)c3d::preload_f64_unit(); break;
-            case UNIT_SYM: (void)c3d::preload_sym_unit(); break;
-            default: break;
-        }
-    });
+hipError_t load_one_unit(unsigned u) {
+    switch (u) {
+        case UNIT_DEVICE: return c3d::preload_device_unit();
+        case UNIT_SCORE: return c3d::preload_score_unit();
+        case UNIT_CLUSTER_BASE: return c3d::preload_cluster_base_unit();
+        case UNIT_EMBED: return c3d::preload_embed_unit();
+        case UNIT_F64: return c3d::preload_f64_unit();
+        case UNIT_SYM: return c3d::preload_sym_unit();
+        default: break;
+    }
+    if (u >= UNIT_CLUSTER_TP0 && u < UNIT_COUNT) return c3d::preload_cluster_unit((int)(u - UNIT_CLUSTER_TP0), true);
+    if (u >= UNIT_CLUSTER_P0 && u < UNIT_CLUSTER_TP0) return c3d::preload_cluster_unit((int)(u - UNIT_CLUSTER_P0), false);
+    return hipErrorInvalidValue;
 }
+// Loads the units of `mask` that `device` does not hold yet.  Must be called WITHOUT g_units.rw held by this thread (Entry does so
+// before it takes the shared side; a nested entry finds its units loaded by the outermost one or reports the programming error).
+int ensure_units(int device, unsigned mask) {
+    if (device < 0 || device >= kMaxDevices) return fail(C3D_ERR_INVALID, "device index beyond the 64 this build keeps code-object state for");
+    mask &= kUnitsAll;
+    if ((g_units.loaded[device].load(std::memory_order_acquire) & mask) == mask) return C3D_OK;
+    if (t_entry_depth > 0) return fail(C3D_ERR_HIP, "internal: a code object is wanted inside an entry that did not name it");
+    std::unique_lock<std::shared_mutex> lk(g_units.rw);
+    HIP_TRY(hipSetDevice(device));
+    for (unsigned u = 0; u < UNIT_COUNT; ++u) {
+        if (!(mask & unit_bit(u)) || (g_units.loaded[device].load(std::memory_order_relaxed) & unit_bit(u))) continue;
+        const hipError_t e = load_one_unit(u);
+        if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("loading the code object of the ") + unit_name(u) + " kernels: " + hipGetErrorString(e));
+        g_units.loaded[device].fetch_or(unit_bit(u), std::memory_order_release);
+        g_units.loads.fetch_add(1);
+    }
+    return C3D_OK;
+}
+// the units the context's current configuration can launch from (the configuration changes through public entries only)
+unsigned units_wanted(const c3d_ctx* c) {
+    unsigned m = unit_bit(UNIT_DEVICE) | unit_bit(UNIT_SCORE);
+    const int pot = std::min(std::max(dev_model(c).noe_pot, 0), 4);
+    if (c->cluster != 0 && c->resident != 0) m |= unit_bit(UNIT_CLUSTER_P0 + (unsigned)pot) | unit_bit(UNIT_CLUSTER_TP0 + (unsigned)pot);
+    if (c->precision == 64) m |= unit_bit(UNIT_F64);
+    if (c->sym > 0) m |= unit_bit(UNIT_SYM);
+    return m;
+}
+// A public entry that issues device work: current device, units present, launch side of the lock — in that order
+struct Entry {
+    int rc = C3D_OK;
+    bool locked = false;
+    explicit Entry(const c3d_ctx* c, unsigned extra = 0) {
+        if (hipSetDevice(c->device) != hipSuccess) { rc = fail(C3D_ERR_HIP, "hipSetDevice failed"); return; }
+        rc = ensure_units(c->device, units_wanted(c) | extra);
+        if (rc != C3D_OK) return;
+        if (t_entry_depth++ == 0) { g_units.rw.lock_shared(); locked = true; }
+    }
+    ~Entry() {
+        if (rc != C3D_OK) return;
+        --t_entry_depth;
+        if (locked) g_units.rw.unlock_shared();
+    }
+    Entry(const Entry&) = delete;
+    Entry& operator=(const Entry&) = delete;
+};
+#define C3D_ENTRY(c, extra)             \
+    Entry entry__((c), (extra));        \
+    if (entry__.rc != C3D_OK) return entry__.rc
 
 bool use_sym(const c3d_ctx* c) {
     if (!c->d_sym_scratch) return false;
@@ -448,7 +517,6 @@ void model_host64(const c3d_ctx* c, double (&mh)[15]) {
 }
 // fp64 target matrix from the resident integer tenths, in the encoding the current model's kernel expects (c3d_f64.hip pair64)
 int build_targets64(c3d_ctx* c) {
-    load_unit(UNIT_F64, c->device);
     double mh[15];
     model_host64(c, mh);
     hipError_t e = c3d::launch_targets64(dev_model(c), mh, c->model.min_sep, c->b64.t10, c->b64.T, c->stream);
@@ -528,7 +596,6 @@ void account_ops(c3d_ctx* c, size_t nops) {
 
 
 int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
-    load_unit(UNIT_CLUSTER, c->device);
     if (c->prog_dirty) {
         if (c->prog_runs.size() > c->prog_cap) {
             if (c->d_prog) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_prog); c->d_prog = nullptr; }
@@ -557,7 +624,6 @@ int run_cluster(c3d_ctx* c, size_t nops, bool* ran) {
     pl.two_point = false;
     for (size_t k = 0; k < nops && !pl.two_point; ++k) pl.two_point = c->program[c->pc + k].p.kind >= 5;
     c->last_two_point = pl.two_point;
-    if (pl.two_point) load_unit(UNIT_CLUSTER_TP, c->device);
     c->inject_misplaced = false;
     c->h_tmo[2] = 0;
     const auto h0 = std::chrono::steady_clock::now();
@@ -635,10 +701,6 @@ int ensure_group_streams(c3d_ctx* c, int G) {
 
 int run_ops_segment(c3d_ctx* c, size_t nops, bool zero_w) {
     if (nops == 0) return C3D_OK;
-    load_unit(UNIT_DEVICE, c->device);
-    if (c->precision == 64) load_unit(UNIT_F64, c->device);
-    else if (use_sym(c)) load_unit(UNIT_SYM, c->device);
-    if (c->preload.joinable()) c->preload.join();      // c3d_create's helper: the kernels it loads are wanted now
     if (c->precision == 64 || zero_w) { }                                           // fp64: the per-step path below (k64_step), never the cluster kernel
     else if (c->resident_skip > 0 && c->resident < 1) --c->resident_skip;     // cooling off after an abandoned launch
     else if (nops >= (size_t)c->resident_min_ops && nops < ((size_t)1 << 20)) {
@@ -793,7 +855,6 @@ int partials_finite(c3d_ctx* c, bool* ok) {
 
 // fp64 state <- the fp32 coordinates of the current parity (start structures, c3d_set_coords, the DG embedding); velocities zero
 int import64(c3d_ctx* c) {
-    load_unit(UNIT_F64, c->device);
     hipError_t e = c3d::launch_import64(dev_model(c), c->buf.X[c->parity], c->b64, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("fp64 import: ") + hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -870,7 +931,11 @@ static std::atomic<int> g_preload{1};
 
 extern "C" int c3d_set_process_option(const char* key, double value) {
     if (!key) return fail(C3D_ERR_INVALID, "c3d_set_process_option: null key");
-    if (!strcmp(key, "preload")) { g_preload.store(value != 0); return C3D_OK; }
+    if (!strcmp(key, "preload")) {
+        if (value != 0 && value != 1 && value != 2) return fail(C3D_ERR_INVALID, "c3d_set_process_option: preload is 0, 1 or 2");
+        g_preload.store((int)value);
+        return C3D_OK;
+    }
     return fail(C3D_ERR_INVALID, std::string("c3d_set_process_option: unknown key ") + key);
 }
 
@@ -910,34 +975,21 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
         c3d_destroy(c);
         return fail(C3D_ERR_HIP, "cannot create HIP stream/events");
     }
-    // The first launch from a translation unit loads its code object (2-3 ms for K1's, 3 ms for the shipped potential's multi-step kernels — 9-13 ms while all five potentials shared one unit) inside the
-    // first job of a process — the reference's usage is one process per matrix.  A helper thread loads the three units a job runs now, once per
-    // process and device, while the caller reads and parses its matrix (first anneal of a process: 31-64 -> 21 ms; 12.8, the steady figure,
-    // with c3d_init_replicas waiting for its fills; profiles/r04_first_job_latency.txt, which also records that warming the copy path the
-    // same way — the first copy of a process, 7.5 ms inside K1's upload — gained nothing: the caller reaches its own first copy before the
-    // helper is through and waits for it).  Errors are not reported from here: what cannot load fails again, loudly, at its first launch.
-    static std::atomic<unsigned> preloaded{0};
-    const unsigned bit = 1u << (device & 31);
-    if (g_preload.load() && !(preloaded.fetch_or(bit) & bit))
-        c->preload = std::thread([device] {
-            if (hipSetDevice(device) != hipSuccess) return;
-            // one at a time (load_unit).  The multi-step kernels' unit first (3 ms, the largest of the three): it is through before the caller
-            // has parsed its matrix and asks for K1's unit — which it then finds loaded, or loads itself, or waits for while this thread
-            // does.  The twin unit of the final stage's two-point part is NOT loaded here: every HIP call of the caller's K1 phase would
-            // queue behind those 3 ms inside the runtime; the first c3d_run of the process starts that load beside its MD stages (below).
-            load_unit(UNIT_CLUSTER, device);
-            load_unit(UNIT_SCORE, device);
-            load_unit(UNIT_DEVICE, device);
-        });
+    // Code objects ("code objects" above): what a default job launches from is loaded HERE, on this thread, before the caller can launch
+    // anything — not by a helper thread beside the caller's first launches, as in rounds 4-5 (that saved the first job of a process ~9 ms
+    // and is where the one device exception of round 5 was met).  Later contexts of the device find the units loaded (one atomic load).
+    {
+        const int pre = g_preload.load();
+        const int rc = pre ? ensure_units(device, pre >= 2 ? kUnitsAll : kUnitsDefault) : C3D_OK;
+        if (rc != C3D_OK) { c3d_destroy(c); return rc; }
+    }
     *out = c;
     return C3D_OK;
 }
 
 extern "C" void c3d_destroy(c3d_ctx* c) {
     if (!c) return;
-    if (c->preload.joinable()) c->preload.join();
-    if (c->tp_loader.joinable()) c->tp_loader.join();
-    c->ifr.join();
+    c->ifr.release();
     hipSetDevice(c->device);
     for (int g = 0; g < c3d_ctx::kMaxGroups; ++g) if (c->gstream[g]) hipStreamSynchronize(c->gstream[g]);
     drop_graphs(c);
@@ -973,7 +1025,10 @@ extern "C" int c3d_set_model(c3d_ctx* c, const c3d_model* m) {
     c->model.msoexp = msoexp;
     dev_free(c->buf.tgs2);                 // the pre-scaled pair targets of the per-step kernel carry 1 / mrs: rebuilt on demand
     build_program(c);
-    if (c->precision == 64 && c->b64.T) return build_targets64(c);     // the fp64 target matrix encodes "no restraint" per potential
+    if (c->precision == 64 && c->b64.T) {                              // the fp64 target matrix encodes "no restraint" per potential
+        C3D_ENTRY(c, 0u);
+        return build_targets64(c);
+    }
     return C3D_OK;
 }
 
@@ -1083,29 +1138,17 @@ extern "C" int c3d_set_option(c3d_ctx* c, const char* key, double value) {
 
 // 3*npad floats of LDS per workgroup must stay below the 64 KB a launch gets without opt-in
 static constexpr int kMaxBeads = 5120;
+// c3d_set_if_matrix computes the Spearman's IF ranks ahead of c3d_score_replicas up to this many beads (memory: see there)
+static constexpr int kRankPrefetchBeads = 2048;
 
 extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alpha, double K) {
     if (!c || !IF || n < 2) return fail(C3D_ERR_INVALID, "c3d_set_if_matrix: bad arguments");
     if (n > kMaxBeads) return fail(C3D_ERR_INVALID, "c3d_set_if_matrix: more than 5120 beads are not supported by this build");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     free_replica_buffers(c);
     set_dims(c, n);
     const size_t nn = (size_t)n * n;
-    // the Spearman's IF ranks (range 3: spearman_IF_pdb.pl:14, the only range a driver asks for) on a helper thread, beside K1 and the anneal
-    c->ifr.join();
-    c->ifr.valid = false;
-    if (c->prefetch_ranks) {
-        try {
-            c->ifr.matrix.assign(IF, IF + nn);
-            c->ifr.n = n; c->ifr.range = 3;
-            c3d_ctx::IfRanks* const w = &c->ifr;
-            c->ifr.worker = std::thread([w] {
-                try { c3d::if_pair_ranks(w->matrix.data(), w->n, w->range, w->rank, w->m, w->mean, w->saa); w->valid = true; }
-                catch (...) { w->valid = false; }
-            });
-        } catch (...) { c->ifr.valid = false; }          // no memory or no thread: c3d_score_replicas computes the ranks itself
-    }
+    c->ifr.release();                               // (joins the previous matrix's worker; its copies go)
     DevTmp<double> dIF, dP, dpart;
     DevTmp<int32_t> ddist;
     DevTmp<unsigned char> dflags;
@@ -1120,6 +1163,21 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     HIP_TRY(hipMalloc(&dflags.p, nn));
     HIP_TRY(hipMalloc(&dnflag.p, sizeof(unsigned)));
     HIP_TRY(hipMalloc(&c->buf.tgt, sizeof(float) * (size_t)n * c->npad));
+    // The Spearman's IF ranks (range 3: spearman_IF_pdb.pl:14, the only range a driver asks for) on a helper thread, beside K1 and the
+    // anneal — host arithmetic only, no HIP call.  Started once K1's allocations stand (an early error return wastes nothing), and only up to
+    // kRankPrefetchBeads: the worker keeps a copy of the matrix and the rank matrix, 16 bytes per pair, until the next matrix arrives or the
+    // context goes (67 MB at 2048 beads; at the 5120 the library accepts it would be 420 MB per context and ~1 GB while it sorts).
+    if (c->prefetch_ranks && n <= kRankPrefetchBeads) {
+        try {
+            c->ifr.matrix.assign(IF, IF + nn);
+            c->ifr.n = n; c->ifr.range = 3;
+            c3d_ctx::IfRanks* const w = &c->ifr;
+            c->ifr.worker = std::thread([w] {
+                try { c3d::if_pair_ranks(w->matrix.data(), w->n, w->range, w->rank, w->m, w->mean, w->saa); w->valid = true; }
+                catch (...) { w->valid = false; }
+            });
+        } catch (...) { c->ifr.release(); }               // no memory or no thread: c3d_score_replicas computes the ranks itself
+    }
     HIP_TRY(hipMemcpyAsync(dIF.p, IF, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(dnflag.p, 0, sizeof(unsigned), c->stream));
     HIP_TRY(hipMemsetAsync(dflags.p, 0, nn, c->stream));
@@ -1170,17 +1228,15 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     c->R = R;
     c->have_targets = true;
     build_program(c);
-    // K1 is through; callers that write the front-half files next (8-10 ms of host work, no HIP call) hide the twin unit's load behind them
-    kick_two_point_unit(c);
     return C3D_OK;
 }
 
 extern "C" int c3d_set_restraints(c3d_ctx* c, int n, int R, const int32_t* ri, const int32_t* rj, const int32_t* rt10) {
     if (!c || n < 2 || R < 0 || (R > 0 && (!ri || !rj || !rt10))) return fail(C3D_ERR_INVALID, "c3d_set_restraints: bad arguments");
     if (n > kMaxBeads) return fail(C3D_ERR_INVALID, "c3d_set_restraints: more than 5120 beads are not supported by this build");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     free_replica_buffers(c);
+    c->ifr.release();
     set_dims(c, n);
     std::vector<float> enc((size_t)n * c->npad);
     std::fill(enc.begin(), enc.end(), 0.0f);
@@ -1213,8 +1269,7 @@ extern "C" int c3d_num_restraints(const c3d_ctx* c) { return c ? c->R : 0; }
 extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t first_replica) {
     if (!c || nrep < 1) return fail(C3D_ERR_INVALID, "c3d_init_replicas: bad arguments");
     if (!c->have_targets) return fail(C3D_ERR_INVALID, "c3d_init_replicas: set the IF matrix / restraints first");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     if (c->have_replicas && nrep != c->nrep) free_replica_buffers(c);
     c->nrep = nrep; c->seed = seed; c->first_rep = first_replica;
     const size_t nf = c->rep_floats * nrep;
@@ -1359,9 +1414,7 @@ extern "C" int c3d_embed_replicas(c3d_ctx* c, int iters) {
     if (!c || iters < 1) return fail(C3D_ERR_INVALID, "c3d_embed_replicas: bad arguments");
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_embed_replicas: call c3d_init_replicas first");
     if ((size_t)9 * c->n + 16 > 160 * 1024 / sizeof(float)) return fail(C3D_ERR_INVALID, "c3d_embed_replicas: too many beads for the embedding kernel");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
-    load_unit(UNIT_EMBED, c->device);
+    C3D_ENTRY(c, unit_bit(UNIT_EMBED));
     const int n = c->n, nrep = c->nrep;
     const size_t nn = (size_t)n * n;
     DevTmp<float> U, L, D2, v0;
@@ -1390,8 +1443,7 @@ extern "C" int c3d_embed_replicas(c3d_ctx* c, int iters) {
 extern "C" int c3d_set_coords(c3d_ctx* c, const float* xyz) {
     if (!c || !xyz) return fail(C3D_ERR_INVALID, "c3d_set_coords: null argument");
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_set_coords: call c3d_init_replicas first");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     std::vector<float> soa;
     pack(c, xyz, soa, true);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1407,14 +1459,12 @@ static int get_soa(c3d_ctx* c, const float* dev, float* aos) {
 }
 extern "C" int c3d_get_coords(c3d_ctx* c, float* xyz) {
     if (!c || !xyz || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_get_coords: bad state");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     return get_soa(c, c->buf.X[c->parity], xyz);
 }
 extern "C" int c3d_get_velocities(c3d_ctx* c, float* v) {
     if (!c || !v || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_get_velocities: bad state");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     return get_soa(c, c->buf.V[c->parity], v);
 }
 
@@ -1429,8 +1479,7 @@ extern "C" long c3d_steps_done(const c3d_ctx* c) { return c ? c->steps_done : 0;
 extern "C" int c3d_run_steps(c3d_ctx* c, long nsteps, long* done) {
     if (!c || nsteps < 0) return fail(C3D_ERR_INVALID, "c3d_run_steps: bad arguments");
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_run_steps: call c3d_init_replicas first");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     // number of program ops that contain exactly nsteps counted steps (or the rest of the program)
     size_t nops = 0;
     long counted = 0;
@@ -1440,7 +1489,6 @@ extern "C" int c3d_run_steps(c3d_ctx* c, long nsteps, long* done) {
     }
     int rc = begin_timing(c);
     if (rc) return rc;
-    kick_two_point_unit(c);
     rc = run_ops(c, nops);
     if (rc) return rc;
     rc = end_timing(c);
@@ -1451,8 +1499,7 @@ extern "C" int c3d_run_steps(c3d_ctx* c, long nsteps, long* done) {
 
 extern "C" int c3d_centre(c3d_ctx* c) {
     if (!c || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_centre: bad state");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     hipError_t e = c3d::launch_centre(dev_model(c), c->buf, c->parity, c->stream);
     if (e != hipSuccess) return fail(C3D_ERR_HIP, std::string("centre launch: ") + hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1462,8 +1509,7 @@ extern "C" int c3d_centre(c3d_ctx* c) {
 extern "C" int c3d_run(c3d_ctx* c) {
     if (!c) return fail(C3D_ERR_INVALID, "c3d_run: null context");
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_run: call c3d_init_replicas first");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     int rc = begin_timing(c);
     if (rc) return rc;
     const int last_stage = (int)c->stages.size() - 1;
@@ -1474,7 +1520,6 @@ extern "C" int c3d_run(c3d_ctx* c) {
         nfixed = 0;
         while (c->pc + nfixed < c->program.size() && c->program[c->pc + nfixed].stage != last_stage) ++nfixed;
     }
-    kick_two_point_unit(c);
     rc = run_ops(c, nfixed);
     if (rc) return rc;
     if (early) {
@@ -1533,6 +1578,7 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
         // gtol); meaningful after a FIRE step only
         double rms = 0;
         if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_get_stat: rms_force needs replicas");
+        C3D_ENTRY(c, 0u);
         const int rc = max_rms_force(const_cast<c3d_ctx*>(c), &rms);
         if (rc) return rc;
         *value = rms;
@@ -1551,6 +1597,8 @@ extern "C" int c3d_get_stat(const c3d_ctx* c, const char* key, double* value) {
     else if (!strcmp(key, "cluster_helper_waves")) *value = c->cl_ok ? (double)c->cl_plan.helpers : 0.0;
     else if (!strcmp(key, "cluster_wgs_per_cu")) *value = c->cl_ok ? (double)c->cl_plan.wgs_per_cu : 0.0;
     else if (!strcmp(key, "replica_groups")) *value = (double)active_groups(c);
+    else if (!strcmp(key, "units_loaded")) *value = (double)g_units.loads.load();                       // code objects this PROCESS has loaded (all devices)
+    else if (!strcmp(key, "units_loaded_mask")) *value = (double)g_units.loaded[c->device & (kMaxDevices - 1)].load();   // bit per unit, this context's device
     else return fail(C3D_ERR_INVALID, std::string("c3d_get_stat: unknown key ") + key);
     return C3D_OK;
 }
@@ -1572,8 +1620,7 @@ extern "C" const char* c3d_step_kernel_name(const c3d_ctx* c) {
 
 extern "C" int c3d_eval(c3d_ctx* c, float w_all, float w_vdw, float repel_s, float* F, double* e) {
     if (!c || !c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_eval: bad state");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, 0u);
     const c3d::DevModel m = dev_model(c);
     const c3d::DevStep p = dev_step(c, 3, 0.0f, w_all, w_vdw, repel_s, 0.0f);
     if (F) {
@@ -1606,9 +1653,7 @@ extern "C" int c3d_score_replicas(c3d_ctx* c, const double* IF, int range, int32
     if (!c || range < 1) return fail(C3D_ERR_INVALID, "c3d_score_replicas: bad arguments");
     if (!c->have_replicas) return fail(C3D_ERR_INVALID, "c3d_score_replicas: call c3d_init_replicas first");
     if (rho && !IF) return fail(C3D_ERR_INVALID, "c3d_score_replicas: the Spearman coefficient needs the IF matrix");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
-    load_unit(UNIT_SCORE, c->device);
+    C3D_ENTRY(c, unit_bit(UNIT_SCORE));
     const int n = c->n, nrep = c->nrep;
     const unsigned nbins = 1u << 18;      // distances up to 262 A in thousandths
     std::vector<double> rankA;
@@ -1689,8 +1734,7 @@ extern "C" int c3d_rank(c3d_ctx* c, int32_t* rank) {
 // kernel's own store and load on THIS context's stream, all CUs (consumers on the producer's XCD and on every other one).
 extern "C" int c3d_debug_tear16(c3d_ctx* c, int iterations, unsigned long long* unit_reads, unsigned long long* torn, unsigned long long* fresh) {
     if (!c || iterations < 1 || iterations > (1 << 24)) return fail(C3D_ERR_INVALID, "c3d_debug_tear16: bad arguments");
-    HIP_TRY(hipSetDevice(c->device));
-    load_unit(UNIT_DEVICE, c->device);
+    C3D_ENTRY(c, unit_bit(UNIT_CLUSTER_BASE));
     DevTmp<unsigned char> buf;
     DevTmp<unsigned> stop;
     DevTmp<unsigned long long> stats;

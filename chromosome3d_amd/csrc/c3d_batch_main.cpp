@@ -266,6 +266,8 @@ void collect(const std::string& arg, const std::string& pattern, std::vector<Job
 }  // namespace
 
 int main(int argc, char** argv) {
+    // a device exception must reach stderr in the runtime's own words, not end in the GPU-core-dump helper's broken pipe (c3d_solve_main.cpp)
+    setenv("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1", 0);
     Options o;
     std::vector<std::string> inputs;
     std::string pattern;

@@ -680,12 +680,10 @@ template <int POT, int RPW, int NB, int WL, bool LATE>
 static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                              const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                              hipStream_t s) {
-    // per (instantiation, device): more dynamic LDS than the 64 KB a launch gets by default.  Contexts of several host
-    // threads launch concurrently (c3d_batch): the flag is atomic, setting the attribute twice is harmless
     // which of the two kernels this translation unit holds: a unit built with -DC3D_CLUSTER_TP carries k_cluster_tp (ranges that hold
-    // two-point minimiser steps) and nothing else, the others k_cluster alone — a job's first launches load the code object they need
-    // (1.7 MB for the shipped potential, 3 ms), the twin's is loaded by c3d_create's helper afterwards or at the final stage's first launch;
-    // the single-unit build (neither split macro) holds both
+    // two-point minimiser steps) and nothing else, the others k_cluster alone; the single-unit build (neither split macro) holds both.
+    // Nothing is set up here: the unit was loaded, and every instantiation given its dynamic LDS size, by cluster_prepare_unit below —
+    // before this process's first launch on the device, under the loader's exclusive lock (c3d_api.cpp "code objects")
 #if defined(C3D_CLUSTER_TP)
     constexpr bool kHasLean = false, kHasTp = true;
 #elif defined(C3D_CLUSTER_POT)
@@ -693,18 +691,8 @@ static hipError_t cluster_go(const DevModel& m, const DevFire& fp, const Cluster
 #else
     constexpr bool kHasLean = true, kHasTp = true;
 #endif
-    static std::atomic<bool> attr_set[2][64];
-    const int dev = pl.device & 63;
     const int tp = pl.two_point ? 1 : 0;         // the range holds two-point minimiser steps: the kernel that carries their row update
     if ((tp && !kHasTp) || (!tp && !kHasLean)) return hipErrorInvalidValue;
-    if (!attr_set[tp][dev].load(std::memory_order_acquire)) {
-        std::lock_guard<std::mutex> lk(code_object_mutex());
-        hipError_t e = hipSuccess;
-        if constexpr (kHasTp) { if (tp) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_tp<POT, RPW, NB, WL, LATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-        if constexpr (kHasLean) { if (!tp) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, RPW, NB, WL, LATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-        if (e != hipSuccess) return e;
-        attr_set[tp][dev].store(true, std::memory_order_release);
-    }
     const int sp = (pl.static_place & 0xff) | ((pl.xcd_base & 0xff) << 8) | ((pl.xcd_count & 0xff) << 16);      // decoded at the kernel's top
 #define C3D_CL_LAUNCH(K)                                                                                                                              \
     do {                                                                                                                                              \
@@ -751,6 +739,40 @@ static hipError_t cluster_geom(const DevModel& m, const DevFire& fp, const Clust
     return hipErrorInvalidValue;
 }
 
+// Loads the code object that holds this unit's kernels on the CURRENT device and allows every instantiation in it the dynamic LDS a
+// launch may ask for (more than the 64 KB a kernel gets by default; hipFuncSetAttribute is per function and device).  Called once per
+// (unit, device) by the loader of c3d_api.cpp while it holds its lock exclusively: after it, a launch from this unit changes no state of
+// the runtime.  Walks the table cluster_geom dispatches over.
+template <int POT, bool TP>
+static hipError_t cluster_prepare_unit() {
+    hipError_t e = hipSuccess;
+#define C3D_PREP1(R, B, W, L)                                                                                            \
+    do {                                                                                                                 \
+        if (e == hipSuccess) {                                                                                           \
+            if constexpr (TP) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_tp<POT, R, B, W, L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<POT, R, B, W, L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        }                                                                                                                \
+    } while (0)
+#define C3D_PREP_W(R, B, W)                                                                                              \
+    do {                                                                                                                 \
+        C3D_PREP1(R, B, W, false);                                                                                       \
+        if constexpr (cluster_late_ok(POT, R, B, W)) C3D_PREP1(R, B, W, true);                                           \
+    } while (0)
+#define C3D_PREP(R, B)                                                                                                   \
+    do {                                                                                                                 \
+        C3D_PREP_W(R, B, 4);                                                                                             \
+        if constexpr (POT >= 3) { C3D_PREP_W(R, B, 3); C3D_PREP_W(R, B, 2); C3D_PREP_W(R, B, 1); }                      \
+    } while (0)
+    C3D_PREP(1, 1); C3D_PREP(1, 2); C3D_PREP(1, 3); C3D_PREP(1, 4);
+    C3D_PREP(2, 1); C3D_PREP(2, 2); C3D_PREP(2, 3); C3D_PREP(2, 4);
+    C3D_PREP(3, 1); C3D_PREP(3, 2);
+    C3D_PREP(4, 1); C3D_PREP(4, 2);
+#undef C3D_PREP
+#undef C3D_PREP_W
+#undef C3D_PREP1
+    return e;
+}
+
 #define C3D_CL_CAT2(a, b) a##b
 #define C3D_CL_CAT(a, b) C3D_CL_CAT2(a, b)
 #if defined(C3D_CLUSTER_POT) && defined(C3D_CLUSTER_TP)
@@ -760,21 +782,15 @@ hipError_t C3D_CL_CAT(launch_cluster_tp_pot, C3D_CLUSTER_POT)(const DevModel& m,
                           hipStream_t s) {
     return cluster_geom<C3D_CLUSTER_POT>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
 }
-hipError_t C3D_CL_CAT(preload_cluster_tp_pot, C3D_CLUSTER_POT)() {
-    hipFuncAttributes a;
-    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_cluster_tp<C3D_CLUSTER_POT, 2, 2, 4, false>));
-}
+hipError_t C3D_CL_CAT(preload_cluster_tp_pot, C3D_CLUSTER_POT)() { return cluster_prepare_unit<C3D_CLUSTER_POT, true>(); }
 #elif defined(C3D_CLUSTER_POT)
-// one potential's unit: its dispatch and one of its kernels to touch (preload)
+// one potential's unit: its dispatch and its preparation (load + LDS attribute of every kernel in it)
 hipError_t C3D_CL_CAT(launch_cluster_pot, C3D_CLUSTER_POT)(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim,
                           hipStream_t s) {
     return cluster_geom<C3D_CLUSTER_POT>(m, fp, pl, io, tgt, rec, runs, run0, skip0, nsteps, tag_base, timeout, claim, s);
 }
-hipError_t C3D_CL_CAT(preload_cluster_pot, C3D_CLUSTER_POT)() {
-    hipFuncAttributes a;
-    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_cluster<C3D_CLUSTER_POT, 2, 2, 4, false>));
-}
+hipError_t C3D_CL_CAT(preload_cluster_pot, C3D_CLUSTER_POT)() { return cluster_prepare_unit<C3D_CLUSTER_POT, false>(); }
 #else
 #if defined(C3D_CLUSTER_SPLIT)
 #define C3D_CL_DECL(P) hipError_t launch_cluster_pot##P(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec, const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout, unsigned* claim, hipStream_t s); hipError_t preload_cluster_pot##P();
@@ -808,28 +824,33 @@ AnnealIO anneal_io(const DevBuffers& b, int parity) {
     return io;
 }
 
-std::mutex& code_object_mutex() {
-    static std::mutex mu;
-    return mu;
-}
-// the unit of the shipped potential (device potential 4): what a default job launches
-hipError_t preload_cluster_unit() {
-    std::lock_guard<std::mutex> lk(code_object_mutex());
+// the unit that holds the multi-step kernels of device potential `pot` — k_cluster (two_point false) or k_cluster_tp —, loaded and
+// prepared on the current device (cluster_prepare_unit); pot outside 0..4 is an error
+hipError_t preload_cluster_unit(int pot, bool two_point) {
 #if defined(C3D_CLUSTER_SPLIT)
-    return preload_cluster_pot4();
+    switch (pot) {
+        case 0: return two_point ? preload_cluster_tp_pot0() : preload_cluster_pot0();
+        case 1: return two_point ? preload_cluster_tp_pot1() : preload_cluster_pot1();
+        case 2: return two_point ? preload_cluster_tp_pot2() : preload_cluster_pot2();
+        case 3: return two_point ? preload_cluster_tp_pot3() : preload_cluster_pot3();
+        case 4: return two_point ? preload_cluster_tp_pot4() : preload_cluster_pot4();
+        default: return hipErrorInvalidValue;
+    }
 #else
+    switch (pot) {
+        case 0: return two_point ? cluster_prepare_unit<0, true>() : cluster_prepare_unit<0, false>();
+        case 1: return two_point ? cluster_prepare_unit<1, true>() : cluster_prepare_unit<1, false>();
+        case 2: return two_point ? cluster_prepare_unit<2, true>() : cluster_prepare_unit<2, false>();
+        case 3: return two_point ? cluster_prepare_unit<3, true>() : cluster_prepare_unit<3, false>();
+        case 4: return two_point ? cluster_prepare_unit<4, true>() : cluster_prepare_unit<4, false>();
+        default: return hipErrorInvalidValue;
+    }
+#endif
+}
+// the planner's own unit: k_tear16 (c3d_debug_tear16) and nothing else in the split build
+hipError_t preload_cluster_base_unit() {
     hipFuncAttributes a;
     return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_tear16));
-#endif
-}
-// the twin unit of the shipped potential (k_cluster_tp: the final stage's two-point part)
-hipError_t preload_cluster_tp_unit() {
-    std::lock_guard<std::mutex> lk(code_object_mutex());
-#if defined(C3D_CLUSTER_SPLIT)
-    return preload_cluster_tp_pot4();
-#else
-    return hipSuccess;
-#endif
 }
 #endif  // C3D_CLUSTER_POT
 

@@ -328,17 +328,15 @@ hipError_t launch_dg_embed(const float* tgt, int n, int npad, int nrep, float b0
     hipLaunchKernelGGL(k_dg_trial, dim3(n, nrep), dim3(256), 0, s, U, L, n, (uint32_t)(seed & 0xFFFFFFFFu),
                        (uint32_t)(seed >> 32), first_replica, D2);
     const size_t lds = sizeof(float) * ((size_t)9 * n + 16);
-    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: opt in (160 KB per CU on gfx950)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dg_eig), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    // (above 64 KB of dynamic LDS a kernel needs an allowance: preload_embed_unit set it when the unit was loaded)
     hipLaunchKernelGGL(k_dg_eig, dim3(nrep), dim3(kEigBlock), lds, s, D2, v0, n, npad, iters, x0, x1);
     return hipGetLastError();
 }
 
+// loads the unit's code object on the current device and allows k_dg_eig the whole LDS of a CU (c3d_api.cpp "code objects": once per
+// device, never beside a launch)
 hipError_t preload_embed_unit() {
-    hipFuncAttributes a;
-    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_dg_clamp));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_dg_eig), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 }  // namespace c3d

@@ -1,7 +1,6 @@
 // c3d_internal.h — shared between the HIP kernels (c3d_device.hip) and the C-ABI host (c3d_api.cpp).
 // Not part of the public boundary (that is include/c3d.h).
 #pragma once
-#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -137,21 +136,18 @@ size_t cluster_record_bytes(const DevModel& m, const ClusterPlan& pl);
 hipError_t launch_cluster(const DevModel& m, const DevFire& fp, const ClusterPlan& pl, const AnnealIO& io, const float* tgt, void* rec,
                           const StepRun* runs, int run0, int skip0, int nsteps, unsigned tag_base, unsigned* timeout,
                           unsigned* claim, hipStream_t s);
-// the hand-off's 16-byte atomicity, watched: one producer workgroup, one consumer workgroup on every other CU (c3d_cluster.hip k_tear16)
-// Code objects are loaded on the first use of one of their kernels, one object per translation unit (K1's 2-3 ms, the shipped potential's
-// multi-step kernels 3 ms, scoring 0.3 ms).  These touch one kernel of their unit so that c3d_create can have them loaded on a helper thread
-// while the caller parses its input.
-// (first touches of the multi-step kernels' code objects — the helper thread's and every context's hipFuncSetAttribute before its first launch
-//  of an instantiation — go one at a time: eight contexts of one process starting at once, c3d_batch --devices 4 --lanes 2 --map-devices-to 0,
-//  crashed in the runtime's lazy loading of the unit once it held twice the kernels, round 5)
-std::mutex& code_object_mutex();
+// Code objects.  The runtime loads a code object at the first use of one of its kernels; libc3d does not leave that to chance: every
+// translation unit that holds kernels exports a function that loads its code object on the current device (and, for the multi-step
+// units, gives every instantiation its dynamic-LDS allowance), and the loader of c3d_api.cpp ("code objects") calls them one at a time,
+// under a lock that every launching entry of the library holds shared — no code object is loaded while a thread of the process can launch.
 hipError_t preload_device_unit();
-hipError_t preload_cluster_unit();
-hipError_t preload_cluster_tp_unit();
+hipError_t preload_cluster_base_unit();
+hipError_t preload_cluster_unit(int pot, bool two_point);
 hipError_t preload_score_unit();
 hipError_t preload_embed_unit();
 hipError_t preload_f64_unit();
 hipError_t preload_sym_unit();
+// the hand-off's 16-byte atomicity, watched: one producer workgroup, one consumer workgroup on every other CU (c3d_cluster.hip k_tear16)
 hipError_t launch_tear16(int num_cus, void* buf, unsigned* stop, unsigned long long* stats, int iters, hipStream_t s);
 // symmetric-tile step for large N (c3d_sym.hip): every pair once.  tiles = sym_tile_list() uploaded, scratch =
 // sym_scratch_floats() floats of device memory (row-side and column-side partial forces of one step).

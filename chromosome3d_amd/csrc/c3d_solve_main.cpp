@@ -48,6 +48,10 @@ static int fail_exit(const std::string& out_dir) {
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char** argv) {
+    // A device exception (memory fault, queue error) must reach stderr in the runtime's own words: by default ROCr first pipes a GPU core
+    // dump to the helper named in /proc/sys/kernel/core_pattern, and where that helper does not exist the process dies on the broken pipe
+    // (rc -13, "GPU coredump: execvp failed") before the runtime has said WHICH exception — round 5 lost the only evidence of one that way.
+    setenv("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1", 0);          // (0: a user's own setting wins)
     const double t_start = now_s();
     std::string if_path, tbl_path, out_dir, id, seq_arg;
     double K = 11, alpha = 0.5, gtol = 1e-2;

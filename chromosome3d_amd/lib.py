@@ -101,6 +101,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise C3DError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(make -C chromosome3d_amd/csrc). There is no CPU fallback.")
+        # a device exception should reach stderr in the runtime's own words: without this ROCr first pipes a GPU core dump to the helper
+        # of /proc/sys/kernel/core_pattern and, where that does not exist, dies on the broken pipe before it has named the exception
+        # (the CLIs do the same in main(); a user's own setting wins; no effect if the process initialised HIP before this import)
+        os.environ.setdefault("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError if the symbol is not exported

@@ -173,10 +173,14 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
 int c3d_set_option(c3d_ctx* ctx, const char* key, double value);
 
 /* Process-wide switches, to be set before the first c3d_create (no environment variable is read by the library):
- *   preload         1 (default) / 0: the first c3d_create of a process for a device starts a helper thread that loads the code objects of the
- *                   kernels a job runs (K1, the multi-step kernel, scoring) while the caller reads and parses its matrix; without it they load
- *                   at their first launch, inside the first job (2-3 ms each for K1's and the multi-step kernel's unit:
- *                   profiles/r04_first_job_latency.txt).  Results are untouched by it (measurement knob). */
+ *   preload         which code objects c3d_create loads before it returns (the library never leaves a load to the runtime's first-launch
+ *                   path and never loads beside a launch: csrc/c3d_api.cpp "code objects"):
+ *                   1 (default)  what a default job launches from — K1 + per-step unit, both multi-step units of the shipped potential,
+ *                                scoring — about 9 ms, once per process and device;
+ *                   2            all sixteen units (long-lived executors: nothing is ever loaded after the first c3d_create of a device);
+ *                   0            none: each unit at the first entry that needs it (measurement knob).
+ *                   Units beyond the default set (other potentials, fp64, symmetric tiles, embedding) load at the first entry that
+ *                   needs them in every mode, while no other thread of the process is inside a launching entry.  Results are untouched. */
 int c3d_set_process_option(const char* key, double value);
 
 /* --- replicas ----------------------------------------------------------------------- */
@@ -192,6 +196,9 @@ int c3d_embed_replicas(c3d_ctx* ctx, int iters);
 /* overwrite coordinates (n_replicas*n*3, xyz interleaved) — tests and restarts */
 int c3d_set_coords(c3d_ctx* ctx, const float* xyz);
 int c3d_get_coords(c3d_ctx* ctx, float* xyz);
+/* (after a range that ended inside the two-point part of a final stage — kind 5, its first final_minimiser_steps steps — the velocity
+ *  slot holds the previous evaluation's FORCE per bead, kcal/mol/A: that minimiser has no velocities and keeps its history there;
+ *  after MD and FIRE steps it is the velocity in A/ps) */
 int c3d_get_velocities(c3d_ctx* ctx, float* v);
 
 /* --- solve -------------------------------------------------------------------------- */

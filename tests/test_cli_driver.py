@@ -232,7 +232,9 @@ def test_batch_executor_lanes_do_not_change_results(built, tmp_path):
 def test_batch_executor_per_device_lists_and_threads_rehearsed_on_one_gpu(built, tmp_path):
     """c3d_batch --devices N on an N-GPU node (csrc/c3d_batch_main.cpp: LPT over the devices, `lanes` host threads and contexts per
     device) had never executed with N > 1: `--map-devices-to 0` runs that code on this box — four logical devices, two lanes each, all on
-    physical device 0 — and the models equal those of `--devices 1` byte for byte; every logical device got work."""
+    physical device 0 — and the models equal those of `--devices 1` byte for byte; every logical device got work.  A device exception
+    would now arrive here in the runtime's own words (the CLI sets HSA_DISABLE_COREDUMP_ON_EXCEPTION: round 5's one failure of this
+    start came back as rc -13 out of the runtime's core-dump helper, its cause unnamed)."""
     import re
     exe = os.path.join(LIBDIR, "c3d_batch")
     ind = os.path.join(GOLD, "inputs")
@@ -257,12 +259,11 @@ def test_batch_executor_per_device_lists_and_threads_rehearsed_on_one_gpu(built,
         for k in range(1, 6):
             assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["four"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
             assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["paired"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
-    # eight contexts of one process starting at once, again and again: the runtime's lazy loading of code objects is not safe against that,
-    # libc3d takes the first touch of every unit one at a time (c3d_api.cpp load_unit; 2 of 2 such starts crashed before, round 5)
-    for rep in range(6):
-        p = subprocess.run([exe] + mats + ["--out", str(tmp_path / f"again{rep}"), "-m", "6", "--devices", "4", "--lanes", "2", "--map-devices-to", "0"],
-                           capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0 and "0 failed" in p.stdout, (rep, p.returncode, p.stderr[-300:])
+    # (round 5 ran the eight-context start seven times here to see whether its device exception came back; a pass by not reproducing a
+    #  race is no evidence.  Round 6 removed what could race — c3d_create loads every code object a default job needs before it returns,
+    #  no helper thread touches the runtime, loads and launches exclude one another: csrc/c3d_api.cpp "code objects" — and checks THAT on
+    #  the CPU under ThreadSanitizer against a fake HIP layer, tests/test_abi_host.py::test_executor_and_loader_under_thread_sanitizer;
+    #  the start above runs once, like any other test.)
     # --pair 1 (default), three lanes: the small chromosomes annealed on halves of the device, --pair 0: nobody did
     assert " XCDs " in runs["paired"][1] and " XCDs " not in runs["one"][1]
     bad = subprocess.run([exe] + mats[:1] + ["--out", str(tmp_path / "x"), "--map-devices-to", "7"], capture_output=True, text=True)

@@ -37,6 +37,40 @@ def test_k1_and_forces_at_n2500(solver, big):
     assert (np.abs(F.sum(1)).max(1) < 5e-5 * np.abs(F).sum(1).max(1)).all()     # Newton's third law
 
 
+def test_two_point_stage_on_the_wide_per_step_kernel_follows_the_oracle_at_n2500(solver, big):
+    """Config 5's kernel — the per-step kernel's wide form, k_step<4, false, 4, false, 16, true> — through the final stage's kinds
+    (chromosome3D.pl:1790-1803; kinds 6 / 5, the hand-over, 3 / 2) against the CPU restatement at N = 2500 x 2: 8 FIRE steps from the coil,
+    then a kind-5 stage of 15 steps with the hand-over after 9 (round 5 held this form to a property test only for kind 5)."""
+    from chromosome3d_amd import default_fire, default_model, make_stages, pipeline
+    from oracle import oracle as O
+    from tests.util import oracle_fire_from
+    IF, _ = big
+    n = IF.shape[0]
+    stages = [(2, 8, 0.0, 1.0, 1.0, 0.85, 0.0), (5, 15, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    m, fire = default_model(), default_fire()
+    solver.set_option("final_minimiser_steps", 9)
+    O.set_two_point_steps(9)
+    try:
+        solver.set_model(m)
+        d10 = pipeline.IF2dist_new(solver, IF)
+        solver.set_schedule(make_stages(stages), fire)
+        solver.init_replicas(2, 82364, 0)
+        x0 = solver.coords()
+        assert solver.run_steps(10 ** 6) == 23
+        assert "k_step<4, false, 4, false, 16, true>" in solver.step_kernel_name, solver.step_kernel_name
+        x = solver.coords()
+        om, of = oracle_model_from(m, n), oracle_fire_from(fire)
+        for r in range(2):
+            xo, _, ev = O.run_schedule(om, d10, O.make_stages(stages), of, 82364, r, x0=x0[r].astype(np.float64))
+            xc = x[r].astype(np.float64)
+            xc -= xc.mean(0)
+            assert ev == 23
+            assert np.abs(xc - xo).max() < 4e-3, np.abs(xc - xo).max()
+    finally:
+        solver.set_option("final_minimiser_steps", 1000)
+        O.set_two_point_steps(1000)
+
+
 def test_anneal_recovers_synthetic_structure(solver, big):
     """Ground truth is known: after the schedule the model's pair distances correlate with the
     generating structure's (Spearman > 0.9) and Spearman(IF, d) is strongly negative."""

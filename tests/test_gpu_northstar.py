@@ -186,7 +186,8 @@ def test_all_45_the_references_own_assessment_of_our_models(solver):
     """The two numbers the reference prints for every model it builds — restraints satisfied within the relaxation and the summed
     violation (assess_dgsa, chromosome3D.pl:447-485, :581-600; c3d_assess is pinned to its known answers 68/528, 2955.67 and
     10778/101426, 374370.87 in test_output_side / test_gpu_parity) — of OUR best-ranked model against the bundled model, on the same
-    contact.tbl rows.  chr1_500kb: 10.5 % / 10.6 % satisfied, 372 700 / 374 371 summed violation.  Table: profiles/r04_parity_sweep_all45.md."""
+    contact.tbl rows.  chr1_500kb: 10.5 % / 10.6 % satisfied, 372 700 / 374 371 summed violation.  Table: profiles/r05_parity_sweep_all45.md
+    (the shipped model and schedule; the round-4 table of the same name prefix held FIRE's final stage)."""
     reps = {cid: _report(solver, cid) for cid in CIDS}
     sat = np.array([r["assess"]["best"][0] / r["assess"]["ref"][0] for r in reps.values()])
     dev = np.array([r["assess"]["best"][1] / r["assess"]["ref"][1] for r in reps.values()])
@@ -380,7 +381,8 @@ def test_xcd_set_of_a_launch_is_bitwise_neutral(solver):
 def test_final_minimisation_converges_at_the_headline_size(solver):
     """The FIRE stand-in for the reference's <= 150 000-evaluation L-BFGS stage (deck :1790-1803) reaches the gradient
     exit (max RMS force component < 1e-2 kcal/mol/A over all 20 replicas) well inside its 3000-step budget at N = 455
-    (profiles/r02_fire_convergence.txt: Spearman is converged to 5 decimals after ~300 steps, the force after ~2000)."""
+    (profiles/r05_fire_convergence.txt and r05_final_stage_convergence.txt, the shipped model: Spearman is settled to 1e-5 after ~500
+    steps, the largest RMS force is below 1e-2 after 1000-2000)."""
     from chromosome3d_amd import default_fire, default_model, default_schedule, pipeline
     IF = _load("chr1_500kb")
     solver.set_model(default_model())

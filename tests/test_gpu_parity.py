@@ -426,6 +426,48 @@ def test_headline_kernel_follows_the_oracle_at_the_headline_size(solver, O):
         solver.set_option("resident", -1)
 
 
+@pytest.mark.parametrize("resident", [1, 0])
+def test_two_point_kernel_follows_the_oracle_at_the_headline_size(solver, O, resident):
+    """The final stage as the shipped schedule runs it (chromosome3D.pl:1790-1803; kind 5), held to the CPU restatement where it runs:
+    chr1_500kb x 20, a short MD stage away from the coil, then a kind-5 stage of 30 steps with the hand-over to FIRE after 12 of them —
+    the two-point steps on k_cluster_tp (the instantiation every default chr1_500kb anneal spends 1000 steps in; round 5 compared it with
+    the oracle at N <= 96 only), the hand-over (kind 3 at step 12: run_ops splits the range there, FIRE's part re-enters k_cluster), then
+    18 FIRE steps; every one of the 20 replicas, at the hand-over and at the end.  resident = 0: the same through the per-step kernel."""
+    stages = [(0, 12, 0.003, 0.4, 0.003, 0.9, 2000.0), (5, 30, 0.0, 1.0, 1.0, 0.85, 0.0)]
+    solver.set_option("final_minimiser_steps", 12)
+    O.set_two_point_steps(12)
+    try:
+        IF, d10, m, fire = _setup(solver, "chr1_500kb", stages, nrep=20)
+        solver.set_option("resident", resident)
+        x0 = solver.coords()
+        assert solver.run_steps(24) == 24                    # MD + the two-point part
+        if resident:
+            assert solver.step_kernel_name.startswith("c3d::k_cluster_tp<4, 4, 2, 3, "), solver.step_kernel_name
+            assert solver.stat("last_path") == 2 and solver.last_timing()[2] == 2       # two launches: k_cluster (MD), k_cluster_tp
+        else:
+            assert solver.step_kernel_name.startswith("c3d::k_step<"), solver.step_kernel_name
+        x_mid = solver.coords()
+        assert solver.run_steps(10 ** 6) == 18               # the hand-over and FIRE
+        if resident:
+            assert solver.step_kernel_name.startswith("c3d::k_cluster<4, 4, 2, 3, "), solver.step_kernel_name
+        x_end = solver.coords()
+        om, of = oracle_model_from(m, IF.shape[0]), oracle_fire_from(fire)
+        head = [stages[0], (5, 12, 0.0, 1.0, 1.0, 0.85, 0.0)]
+        worst = [0.0, 0.0]
+        for r in range(20):
+            for k, (st, x, nev) in enumerate(((head, x_mid, 24), (stages, x_end, 42))):
+                xo, _, ev = O.run_schedule(om, d10, O.make_stages(st), of, 82364, r, x0=x0[r].astype(np.float64))
+                xc = x[r].astype(np.float64)
+                xc -= xc.mean(0)
+                assert ev == nev
+                worst[k] = max(worst[k], float(np.abs(xc - xo).max()))
+        assert worst[0] < 4e-3 and worst[1] < 4e-3, worst
+    finally:
+        solver.set_option("resident", -1)
+        solver.set_option("final_minimiser_steps", 1000)
+        O.set_two_point_steps(1000)
+
+
 @pytest.mark.parametrize("cid,nsteps", [("chr21_1mb", (60, 250, 120, 150)), ("chr20_1mb", (40, 150, 60, 80))])
 def test_fp64_path_follows_the_oracle_over_long_trajectories(solver, O, cid, nsteps):
     """Option precision = 64 (c3d_f64.hip): the oracle's algorithm in the oracle's precision on the GPU.  Hundreds of

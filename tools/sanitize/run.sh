@@ -1,10 +1,13 @@
 #!/bin/bash
 # AddressSanitizer + UBSan (+ float-cast-overflow) over the host-only translation unit of libc3d, then a ThreadSanitizer
-# build of the same for the threaded matrix parser and concurrent callers of the host helpers (CPU builds; GPU
-# sanitizers are not available on this pool).
+# build of the same for the threaded matrix parser and concurrent callers of the host helpers, then (round 6) ThreadSanitizer over the
+# CONTEXT code and the c3d_batch executor — c3d_api.cpp + c3d_batch_main.cpp as they are, against the fake HIP layer of hip_stub.cpp:
+# eight contexts on one device, 8 devices x 3 lanes, and an API storm through every code object (executor_tsan_main.cpp).
+# CPU builds; GPU sanitizers are not available on this pool.   usage: run.sh [executor]   (executor: the round-6 part alone)
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd)
 TMP=$(mktemp -d)
+if [ "$1" != "executor" ]; then
 MATRIX="$ROOT/tests/golden/inputs/chr21_1mb_matrix.txt"; MODEL=$(ls "$ROOT"/tests/golden/models/chr21_1mb_rank07_a11.pdb)
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined,float-cast-overflow -fno-sanitize-recover=undefined,float-cast-overflow -fno-omit-frame-pointer \
     -o "$TMP/host_asan" "$HERE/host_asan_main.cpp" "$ROOT/chromosome3d_amd/csrc/c3d_host.cpp" -lpthread
@@ -12,4 +15,18 @@ ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 "$TMP/host_asan" "$
 g++ -std=c++17 -O1 -g -fsanitize=thread -fno-omit-frame-pointer \
     -o "$TMP/host_tsan" "$HERE/host_asan_main.cpp" "$ROOT/chromosome3d_amd/csrc/c3d_host.cpp" -lpthread
 TSAN_OPTIONS=halt_on_error=1 "$TMP/host_tsan" "$MATRIX" "$MODEL" "$TMP" tsan
+fi
+# the executor and the context code under TSan, fake HIP layer (no libamdhip64, no kernels)
+CSRC="$ROOT/chromosome3d_amd/csrc"
+TF="-std=c++17 -O1 -g -fsanitize=thread -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Wno-unused-result"
+g++ $TF -c "$CSRC/c3d_api.cpp" -o "$TMP/api.o" &
+g++ $TF -c "$CSRC/c3d_host.cpp" -o "$TMP/host.o" &
+g++ $TF -Dmain=c3d_batch_main -c "$CSRC/c3d_batch_main.cpp" -o "$TMP/batch.o" &
+g++ $TF -c "$HERE/hip_stub.cpp" -o "$TMP/stub.o" &
+g++ $TF -c "$HERE/executor_tsan_main.cpp" -o "$TMP/main.o" &
+wait
+g++ -fsanitize=thread "$TMP/api.o" "$TMP/host.o" "$TMP/batch.o" "$TMP/stub.o" "$TMP/main.o" -o "$TMP/executor_tsan" -lpthread
+mkdir -p "$TMP/run"
+TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1" "$TMP/executor_tsan" "$TMP/run" > "$TMP/executor.log" 2>&1 || { tail -40 "$TMP/executor.log"; rm -rf "$TMP"; exit 1; }
+tail -1 "$TMP/executor.log"
 rm -rf "$TMP"
