@@ -217,6 +217,54 @@ def config4_in_a_child():
     return json.loads(lines[-1])
 
 
+def final_stage_block(device=0):
+    """The final minimisation's two kernels at the headline workload, each as ONE launch with its own start-to-end stamps: the 1000
+    two-point steps on k_cluster_tp and the FIRE steps behind them on k_cluster (median of 3 anneals).  The timed regions of the metric
+    stay in front of that stage (config.L_timed), so its kernels get figures of their own — measured in a child process
+    (`bench.py --final-stage-block`), not under whatever profiler watches the parent: the parent's kernel trace must hold the timed
+    launches only, or its average duration of k_cluster would not be roofline.avg_launch_us."""
+    from chromosome3d_amd import Solver, default_fire, default_model, default_schedule, pipeline
+    from tests.util import load_if
+    s = Solver(device)
+    try:
+        s.set_model(default_model())
+        pipeline.IF2dist_new(s, load_if(WORKLOAD))
+        s.set_schedule(default_schedule(MIN_STEPS), default_fire(), 0.0, 250)
+        L = s.schedule_length
+        s.set_option("kernel_timing", 1)
+        tp, fr, md, names = [], [], [], {}
+        for rep in range(4):
+            s.init_replicas(REPLICAS, 82364, 10 ** 6)
+            s.run_steps(L - MIN_STEPS)
+            md.append(s.stat("last_kernel_us") / (L - MIN_STEPS))
+            s.run_steps(1000)
+            tp.append(s.stat("last_kernel_us") / 1000.0)
+            names["two_point"] = s.step_kernel_name
+            s.run_steps(MIN_STEPS - 1000)
+            fr.append(s.stat("last_kernel_us") / (MIN_STEPS - 1000))
+            names["fire"] = s.step_kernel_name
+        med = lambda v: round(statistics.median(v[1:]), 4)            # the first anneal warms the clocks
+        return {"k_cluster_tp": {"kernel": names["two_point"], "us_per_step_kernel": med(tp), "steps_per_launch": 1000,
+                                 "range": f"steps {L - MIN_STEPS} .. {L - MIN_STEPS + 1000} of the schedule (two-point step sizes)"},
+                "k_cluster_fire_part": {"kernel": names["fire"], "us_per_step_kernel": med(fr), "steps_per_launch": MIN_STEPS - 1000,
+                                        "range": f"steps {L - MIN_STEPS + 1000} .. {L} (FIRE after the hand-over)"},
+                "k_cluster_before_final_stage": {"us_per_step_kernel": med(md), "steps_per_launch": L - MIN_STEPS,
+                                                 "range": f"steps 0 .. {L - MIN_STEPS} in one launch (FIRE 200, hot MD 1000, cool MD 972)"},
+                "note": f"{WORKLOAD} x {REPLICAS}, one GPU, kernel start-to-end stamps of one launch each, median of 3 anneals; a child process; not part of `value`"}
+    finally:
+        s.close()
+
+
+def final_stage_in_a_child():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS")) and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--final-stage-block"], capture_output=True, text=True, cwd=ROOT, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": (p.stdout + p.stderr)[-300:]}
+    return json.loads(lines[-1])
+
+
 def end_to_end(IF):
     """The user-facing path of chromosome3D.pl for the headline matrix, as a child process: c3d_batch on chr1_500kb's text matrix —
     parse -> K1 -> <ID>.dist/.rr/contact.tbl/.fasta -> 20 start structures -> anneal -> read-back, ranking, Spearman -> 20 PDB files,
@@ -280,6 +328,7 @@ def main():
                     help="f64: the fp64 reference step (c3d_f64.hip, written for clarity) instead of the fp32 product kernels")
     ap.add_argument("--dist", action="store_true", help="initialise the torch.distributed process group even at one rank (RCCL path on a one-GPU box)")
     ap.add_argument("--no-side-figures", action="store_true", help="skip the f64 leg and the config 2 / config 5 step rates (rank 0, one GPU only)")
+    ap.add_argument("--final-stage-block", action="store_true", help="internal: print the final stage's kernel figures as one JSON line and exit (final_stage_in_a_child)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", type=int, default=REPLICAS, help="weak: per GPU; strong: in all")
@@ -288,6 +337,9 @@ def main():
     ap.add_argument("--rpw", type=int, default=0, help="rows per wave of the step kernel (tuning knob; 0 = library default)")
     args = ap.parse_args()
     reps = args.reps or (50 if args.steps <= 100 else 5)
+    if args.final_stage_block:
+        print(json.dumps(final_stage_block()), flush=True)
+        return
 
     # --gpus N: either the caller started N ranks (WORLD_SIZE == N, checked) or this process starts them as children and
     # relays their output — before anything here has touched HIP (chromosome3d_amd/launch.py)
@@ -503,7 +555,8 @@ def main():
         traffic, traffic_src = hbm_traffic_from_profiles(kernel, n, M)
         out = {
             "metric": f"SA-steps/sec (replica-steps/s, {total_replicas} replicas of chr1_500kb in all: {'+'.join(str(c) for c in per_rank)} per GPU, "
-                      f"{args.scaling} scaling); wall-clock per chromosome",
+                      f"{args.scaling} scaling" + (f"; regions of {args.steps} steps inside the first {L_timed} of the schedule's {L}: MD and FIRE steps in front of the final minimisation"
+                                                  if L_timed < L else "; regions over the whole schedule") + "); wall-clock per chromosome",
             "value": round(value, 1),
             "unit": "replica-steps/s",
             "n_gpus": world,
@@ -522,7 +575,7 @@ def main():
             "config": {"workload": f"{WORKLOAD}: N={n} beads, R={R} restraints, {total_replicas} replicas in all "
                                    f"({'+'.join(str(c) for c in per_rank)} per GPU), default schedule "
                                    f"(200 FIRE + 1000 hot MD + 972 cool MD + {MIN_STEPS} final minimisation [1000 two-point steps, then FIRE; no early exit here] = {L} steps; the timed regions lie in the first {L_timed})",
-                       "replicas_per_gpu": per_rank, "parallelism": f"replica-sharded x{world}",
+                       "replicas_per_gpu": per_rank, "parallelism": f"replica-sharded x{world}", "schedule_steps": L, "L_timed": L_timed,
                        "launch": {2: "one multi-step cluster launch per region", 0: "eager" if args.no_graph else "hipGraph",
                                   3: "fp64: one k64_step launch per step and replica group, hipGraph"}.get(path, "?")},
             "reps": reps,
@@ -544,6 +597,11 @@ def main():
             "multi_step_launches_abandoned": int(fallbacks_in_timed),
             "wall_s_per_chromosome_full_schedule": round(full_wall, 5),
             "device_ms_full_schedule": round(full_dev_ms, 3),
+            # every stage of the schedule, the final minimisation's two kernels included, in calls of --steps: the figure to compare rounds on
+            # (rounds 1-4 sampled the final stage inside `value` at default arguments, rounds 5-6 do not: BASELINE.md section 5)
+            "whole_schedule": {"value": round(total_replicas * L / full_wall, 1), "value_device": round(total_replicas * L / (1e-3 * full_dev_ms), 1),
+                               "unit": "replica-steps/s", "steps": L, "calls_of": args.steps,
+                               "note": "one complete fixed-length anneal (no exit test), wall = host clock around the calls, device = HIP-event pairs; max over ranks"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950
@@ -577,6 +635,8 @@ def main():
         if c4 is not None:
             out["config4"] = c4
         if world == 1 and not args.no_side_figures and args.dtype == "f32":
+            if path == 2:
+                out["other_kernels"] = final_stage_in_a_child()
             out.update(side_figures(local_rank, IF, model, fire, stages, args, B))
             e2e = end_to_end(IF)
             if e2e is not None:

@@ -17,9 +17,9 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <condition_variable>
 #include <map>
 #include <mutex>
-#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -427,8 +427,38 @@ constexpr unsigned unit_bit(unsigned u) { return 1u << u; }
 constexpr unsigned kUnitsDefault = unit_bit(UNIT_DEVICE) | unit_bit(UNIT_SCORE) | unit_bit(UNIT_CLUSTER_P0 + 4) | unit_bit(UNIT_CLUSTER_TP0 + 4);
 constexpr unsigned kUnitsAll = (1u << UNIT_COUNT) - 1u;
 constexpr int kMaxDevices = 64;
+// launches share it, loads own it; a waiting load goes first (std::shared_mutex on glibc prefers readers: with three lanes of a device
+// overlapping their entries, the first c3d_create of the NEXT device could wait for a gap that never comes)
+class LaunchGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int launching = 0, loads_waiting = 0;
+    bool loading = false;
+public:
+    void lock_shared() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !loading && loads_waiting == 0; });
+        ++launching;
+    }
+    void unlock_shared() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--launching == 0) cv.notify_all();
+    }
+    void lock() {
+        std::unique_lock<std::mutex> lk(mu);
+        ++loads_waiting;
+        cv.wait(lk, [&] { return !loading && launching == 0; });
+        --loads_waiting;
+        loading = true;
+    }
+    void unlock() {
+        std::lock_guard<std::mutex> lk(mu);
+        loading = false;
+        cv.notify_all();
+    }
+};
 struct Units {
-    std::shared_mutex rw;
+    LaunchGate rw;
     std::atomic<unsigned> loaded[kMaxDevices];     // bit u: unit u is loaded (and prepared) on that device
     std::atomic<long> loads{0};                    // units loaded by this process (stat "units_loaded": a test reads it)
     Units() { for (auto& a : loaded) a.store(0); }
@@ -462,7 +492,7 @@ int ensure_units(int device, unsigned mask) {
     mask &= kUnitsAll;
     if ((g_units.loaded[device].load(std::memory_order_acquire) & mask) == mask) return C3D_OK;
     if (t_entry_depth > 0) return fail(C3D_ERR_HIP, "internal: a code object is wanted inside an entry that did not name it");
-    std::unique_lock<std::shared_mutex> lk(g_units.rw);
+    std::lock_guard<LaunchGate> lk(g_units.rw);
     HIP_TRY(hipSetDevice(device));
     for (unsigned u = 0; u < UNIT_COUNT; ++u) {
         if (!(mask & unit_bit(u)) || (g_units.loaded[device].load(std::memory_order_relaxed) & unit_bit(u))) continue;
