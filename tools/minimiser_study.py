@@ -80,6 +80,55 @@ def bb_lag(fg, x, maxeval=6000, max_move=0.5):
     return x, fg(x)[0], ne
 
 
+def _compact_direction(g_now, S, Y, p_s, p_y, gamma):
+    """-H g for the compact (Byrd-Nocedal-Schnabel 1994) form H = gamma I + [S gamma Y] M [S' ; gamma Y'] with the projections S'g, Y'g handed in:
+    p_s, p_y may be those of the CURRENT gradient (a mid-step global sum) or of the previous one (what the kernel's replica sums are)."""
+    m = len(S)
+    if m == 0:
+        return -gamma * g_now
+    Sm, Ym = np.array(S), np.array(Y)
+    SY = Sm @ Ym.T                                   # s_i . y_j
+    R = np.triu(SY)
+    D = np.diag(np.diag(SY))
+    YY = Ym @ Ym.T
+    Rinv = np.linalg.inv(R)
+    # H = gamma I + [S gamma Y] [[Rinv' (D + gamma YY) Rinv, -Rinv'], [-Rinv, 0]] [S' ; gamma Y']
+    top = Rinv.T @ ((D + gamma * YY) @ (Rinv @ p_s)) - Rinv.T @ (gamma * p_y)
+    bot = -Rinv @ p_s
+    return -(gamma * g_now + Sm.T @ top + gamma * (Ym.T @ bot))
+
+
+def lbfgs_fixed_step(fg, x, m=5, maxeval=6000, max_move=0.5, late=False):
+    """L-BFGS without a line search and without an energy — what a kernel step can afford: the quasi-Newton direction at unit length, every
+    bead's move capped at max_move (as FIRE and the two-point steps are), a pair (s, y) kept when its curvature is positive, the memory
+    dropped when the direction is not a descent direction.  late = False: the 2m projections S'g, Y'g are those of THIS evaluation's gradient
+    — in the multi-step kernel a second global sum per step, between the force evaluation and the move.  late = True: the projections of
+    the PREVIOUS evaluation's gradient (no second sum: how the kernel's replica sums arrive) with the current gradient in the gamma I term."""
+    _, g = fg(x); ne = 1; S, Y = [], []
+    gamma = max_move / max(np.abs(g).max(), 1e-30) * 0.1
+    g_prev = g.copy()
+    while rms(g) >= GT and ne < maxeval:
+        gp = g_prev if late else g
+        ps = np.array([s_.dot(gp) for s_ in S]); py = np.array([y_.dot(gp) for y_ in Y])
+        d = _compact_direction(g, S, Y, ps, py, gamma)
+        if g.dot(d) >= 0:                                # not downhill: forget the memory
+            S, Y = [], []
+            d = -gamma * g
+        step = d.reshape(-1, 3)
+        ln = np.sqrt((step ** 2).sum(axis=1)); step = step * np.minimum(1.0, max_move / np.maximum(ln, 1e-30))[:, None]
+        xn = x + step.ravel(); _, gn = fg(xn); ne += 1
+        s_ = xn - x; y_ = gn - g; sy = s_.dot(y_)
+        if sy > 1e-12 * np.sqrt(s_.dot(s_) * y_.dot(y_)):
+            S.append(s_); Y.append(y_)
+            if len(S) > m: S.pop(0); Y.pop(0)
+            gamma = sy / y_.dot(y_)
+        else:
+            S, Y = [], []
+            gamma *= 2.0
+        g_prev = g; x, g = xn, gn
+    return x, fg(x)[0], ne
+
+
 def cg(fg, x, maxeval=6000, max_move=0.5):
     f, g = fg(x); ne = 1; d = -g; t = max_move / max(np.abs(g).max(), 1e-30) * 0.1
     while rms(g) >= GT and ne < maxeval:
@@ -96,7 +145,37 @@ def cg(fg, x, maxeval=6000, max_move=0.5):
     return x, f, ne
 
 
+def study_fixed_step(nrep, cids):
+    """Round 6: would L-BFGS pay in the multi-step kernel?  Evaluations to the exit test for the two forms a kernel
+    step could take — no energy, no line search — against the two-point steps that ship (length one evaluation late) and the textbook L-BFGS."""
+    s = Solver(0)
+    print("| matrix | N | replica | two-point, length late (ships) | L-BFGS m=5, Armijo (evaluations) | L-BFGS m=5 fixed step, projections of THIS gradient | same, m=3 | "
+          "L-BFGS m=5 fixed step, projections one evaluation LATE |\n|" + "---|" * 8)
+    tot = np.zeros(5)
+    for cid in cids:
+        IF = load_if(cid); n = IF.shape[0]
+        rows = [(t.kind, t.nsteps, t.dt, t.w_all, t.w_vdw, t.repel_s, t.t_bath) for t in default_schedule(3000)]
+        m = default_model(); s.set_model(m); d10 = pipeline.IF2dist_new(s, IF)
+        s.set_schedule(make_stages(rows[:-1]), default_fire(), 0.0, 250); s.init_replicas(nrep, 82364, 0); s.run()
+        x0 = s.coords()
+        om = oracle_model_from(m, n); w_all, w_vdw, rs = rows[-1][3], rows[-1][4], rows[-1][5]
+        def fg(u):
+            F, e = O.energy_force(om, d10, u.reshape(n, 3), w_all, w_vdw, rs)
+            return w_all * (e[0] + e[1]) + w_vdw * e[2], -F.ravel()
+        for r in range(nrep):
+            u = x0[r].astype(np.float64).ravel()
+            n_bb = bb_lag(fg, u)[2]; n_l = lbfgs(fg, u)[2]; n_f5 = lbfgs_fixed_step(fg, u, 5)[2]; n_f3 = lbfgs_fixed_step(fg, u, 3)[2]
+            n_late = lbfgs_fixed_step(fg, u, 5, late=True)[2]
+            tot += (n_bb, n_l, n_f5, n_f3, n_late)
+            print(f"| {cid} | {n} | {r} | {n_bb} | {n_l} | {n_f5} | {n_f3} | {n_late} |", flush=True)
+    print(f"# totals: two-point late {tot[0]:.0f}; L-BFGS Armijo {tot[1]:.0f} ({tot[0] / tot[1]:.2f}x fewer); fixed step m=5 {tot[2]:.0f} ({tot[0] / tot[2]:.2f}x); "
+          f"m=3 {tot[3]:.0f} ({tot[0] / tot[3]:.2f}x); projections late {tot[4]:.0f} ({tot[0] / tot[4]:.2f}x)   (6000 = did not converge)")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "fixed":
+        study_fixed_step(int(sys.argv[2]) if len(sys.argv) > 2 else 4, sys.argv[3:] or ["chr21_1mb", "chr13_1mb", "chr4_1mb", "chr10_500kb", "chr1_500kb"])
+        sys.exit(0)
     nrep = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     cids = sys.argv[2:] or ["chr21_1mb", "chr13_1mb", "chr4_1mb", "chr10_500kb", "chr1_500kb"]
     s = Solver(0)
