@@ -1178,7 +1178,28 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     free_replica_buffers(c);
     set_dims(c, n);
     const size_t nn = (size_t)n * n;
-    c->ifr.release();                               // (joins the previous matrix's worker; its copies go)
+    // The Spearman's IF ranks (range 3: spearman_IF_pdb.pl:14, the only range a driver asks for) on a helper thread, beside K1 and the
+    // anneal — host arithmetic only, no HIP call.  Only up to kRankPrefetchBeads: the worker keeps a copy of the matrix and the rank matrix,
+    // 16 bytes per pair, until the context goes (67 MB at 2048 beads; at the 5120 the library accepts it would be 420 MB per context and
+    // ~1 GB while it sorts).  It starts HERE, before K1's allocations and copies, and the vectors keep their capacity from matrix to
+    // matrix: started after the allocations (so that an early error return wastes no work: round 6 tried it) the worker's first
+    // milliseconds — page faults of 3 MB of fresh vectors — coincide with K1's upload from pageable memory, and config 4 took 0.39-0.40 s
+    // instead of 0.175 (same box, A/B, profiles/r06_rank_prefetch_start_ab.txt); without the worker at all 0.27-0.33 s.
+    c->ifr.join();
+    c->ifr.valid = false;
+    if (c->prefetch_ranks && n <= kRankPrefetchBeads) {
+        try {
+            c->ifr.matrix.assign(IF, IF + nn);
+            c->ifr.n = n; c->ifr.range = 3;
+            c3d_ctx::IfRanks* const w = &c->ifr;
+            c->ifr.worker = std::thread([w] {
+                try { c3d::if_pair_ranks(w->matrix.data(), w->n, w->range, w->rank, w->m, w->mean, w->saa); w->valid = true; }
+                catch (...) { w->valid = false; }
+            });
+        } catch (...) { c->ifr.release(); }               // no memory or no thread: c3d_score_replicas computes the ranks itself
+    } else {
+        c->ifr.release();                                  // a matrix beyond the limit: the copies of the previous one go
+    }
     DevTmp<double> dIF, dP, dpart;
     DevTmp<int32_t> ddist;
     DevTmp<unsigned char> dflags;
@@ -1193,21 +1214,6 @@ extern "C" int c3d_set_if_matrix(c3d_ctx* c, const double* IF, int n, double alp
     HIP_TRY(hipMalloc(&dflags.p, nn));
     HIP_TRY(hipMalloc(&dnflag.p, sizeof(unsigned)));
     HIP_TRY(hipMalloc(&c->buf.tgt, sizeof(float) * (size_t)n * c->npad));
-    // The Spearman's IF ranks (range 3: spearman_IF_pdb.pl:14, the only range a driver asks for) on a helper thread, beside K1 and the
-    // anneal — host arithmetic only, no HIP call.  Started once K1's allocations stand (an early error return wastes nothing), and only up to
-    // kRankPrefetchBeads: the worker keeps a copy of the matrix and the rank matrix, 16 bytes per pair, until the next matrix arrives or the
-    // context goes (67 MB at 2048 beads; at the 5120 the library accepts it would be 420 MB per context and ~1 GB while it sorts).
-    if (c->prefetch_ranks && n <= kRankPrefetchBeads) {
-        try {
-            c->ifr.matrix.assign(IF, IF + nn);
-            c->ifr.n = n; c->ifr.range = 3;
-            c3d_ctx::IfRanks* const w = &c->ifr;
-            c->ifr.worker = std::thread([w] {
-                try { c3d::if_pair_ranks(w->matrix.data(), w->n, w->range, w->rank, w->m, w->mean, w->saa); w->valid = true; }
-                catch (...) { w->valid = false; }
-            });
-        } catch (...) { c->ifr.release(); }               // no memory or no thread: c3d_score_replicas computes the ranks itself
-    }
     HIP_TRY(hipMemcpyAsync(dIF.p, IF, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(dnflag.p, 0, sizeof(unsigned), c->stream));
     HIP_TRY(hipMemsetAsync(dflags.p, 0, nn, c->stream));
