@@ -25,6 +25,11 @@ MODULE = C3D		PACKAGE = C3D
 
 PROTOTYPES: DISABLE
 
+BOOT:
+    /* a device exception should reach stderr in the runtime's own words, not end in ROCr's GPU-core-dump helper (INTEGRATION.md "Device
+     * exceptions"); set at module load, before the first HIP call of this perl; a user's own setting wins */
+    setenv("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1", 0);
+
 const char*
 last_error()
     CODE:

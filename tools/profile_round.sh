@@ -24,6 +24,12 @@ rocprofv3 --kernel-trace --stats -d $O/trace_f64 -o t --output-format csv -- pyt
 if [ "$2" != "traces" ]; then
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_sq_config5 -o p --output-format csv -- python3 $R/tools/config5_profile_run.py 0 > $O/pmc_sq_config5.log 2>&1
 python3 $R/tools/pmc_summarise.py $O/pmc_sq_config5 k_step > $O/pmc_sq_config5_summary.txt
+# config 5's HBM traffic per step (round 6: the one HBM-streaming configuration; its step time has moved between boxes, 25.4-33 us):
+# a dispatch of the wide per-step kernel = one SA step of a replica group (4 of the 8 replicas)
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_config5 -o p --output-format csv -- python3 $R/tools/config5_profile_run.py 0 > $O/pmc_fetch_config5.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_config5 -o p --output-format csv -- python3 $R/tools/config5_profile_run.py 0 > $O/pmc_write_config5.log 2>&1
+python3 $R/tools/pmc_summarise.py $O/pmc_fetch_config5 $O/pmc_write_config5 k_step --json $O/hbm_traffic_config5_k_step.json --n 2500 --replicas 4 --steps-per-dispatch 1 > $O/pmc_hbm_config5_summary.txt
+(rocm-smi --showclocks 2>/dev/null | grep -i "sclk\|mclk\|fclk" | head -8) > $O/clocks_after_config5.txt 2>&1 || true
 fi
 cd $R
 python tools/trace_check.py $O/trace_default/t_kernel_stats.csv $O/bench_default_under_rocprof.json $O/trace_s20/t_kernel_stats.csv $O/bench_s20_under_rocprof.json > $O/trace_vs_bench.txt
