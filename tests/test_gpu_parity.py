@@ -998,11 +998,13 @@ def test_packed_pair_term_has_the_scalar_forms_bits(solver, cid):
         solver.set_option("eval_rows_per_wave", 4)
 
 
-def test_first_job_helper_and_lazy_group_streams_change_no_bit(built):
-    """c3d_create's helper thread (code objects loaded while the caller parses; include/c3d.h c3d_set_process_option "preload") and the
-    replica-group streams made on first use are latency measures: a fresh process with the helper and one without end a job — K1, 300
-    steps of the default schedule through the multi-step kernel, then 40 steps on the per-step path with two and three replica groups —
-    in the same coordinates, bit for bit."""
+def test_code_objects_load_in_create_or_at_the_entry_that_needs_them_and_change_no_bit(built):
+    """The loader of csrc/c3d_api.cpp ("code objects", round 6; include/c3d.h c3d_set_process_option "preload"): c3d_create loads the four
+    units a default job launches from (preload 1), all sixteen (2) or none (0: each at the first entry that needs it); a potential outside
+    the default set, the fp64 step and the embedding load at the entry that first needs them — counted by the stat `units_loaded` — and
+    none of it touches a result: fresh processes in the three modes end a job — K1, 300 steps of the default schedule through the
+    multi-step kernel, 40 steps on the per-step path with two and three replica groups (their streams are made on first use) — in the same
+    coordinates, bit for bit."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1013,28 +1015,49 @@ import numpy as np
 from chromosome3d_amd import lib
 from chromosome3d_amd.solver import Solver, default_model, default_schedule
 from tests.util import load_if
-if sys.argv[1] == "0":
-    lib.check(lib.load().c3d_set_process_option(b"preload", 0.0))
+lib.check(lib.load().c3d_set_process_option(b"preload", float(sys.argv[1])))
 s = Solver(0)
+counts = [int(s.stat("units_loaded"))]
 s.set_model(default_model())
 s.set_if_matrix(load_if("chr20_1mb"))
 s.set_schedule(default_schedule(3000))
 s.init_replicas(6, seed=5)
 s.run_steps(300)
+counts.append(int(s.stat("units_loaded")))
 h = [hashlib.md5(np.ascontiguousarray(s.coords()).tobytes()).hexdigest(), str(int(s.stat("cluster_launches")))]
 for g in (2, 3):
     s.set_option("resident", 0)
     s.set_option("replica_groups", g)
     s.run_steps(40)
     h.append(hashlib.md5(np.ascontiguousarray(s.coords()).tobytes()).hexdigest())
+s.set_option("resident", -1)
+s.set_model(default_model(noe_pot=1))            # another potential: its two multi-step units, on demand
+s.init_replicas(6, seed=5)
+s.run_steps(30)
+counts.append(int(s.stat("units_loaded")))
+s.set_model(default_model())
+s.set_option("precision", 64)                    # the fp64 unit
+s.set_if_matrix(load_if("chr20_1mb"))
+s.init_replicas(2, seed=5)
+s.embed(10)                                      # and the embedding's
+s.run_steps(10)
+counts.append(int(s.stat("units_loaded")))
+s2 = Solver(0)                                   # a second context of the process loads nothing
+counts.append(int(s2.stat("units_loaded")))
 print("HASH", " ".join(h))
+print("UNITS", " ".join(map(str, counts)))
 ''' % root
-    out = []
-    for flag in ("1", "0"):
+    out, units = [], []
+    for flag in ("1", "0", "2"):
         p = subprocess.run([sys.executable, "-c", code, flag], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
         out.append([l for l in p.stdout.splitlines() if l.startswith("HASH")][-1].split()[1:])
-    assert out[0] == out[1] and int(out[0][1]) >= 1 and len(set(out[0][i] for i in (0, 2, 3))) == 3
+        units.append([int(v) for v in [l for l in p.stdout.splitlines() if l.startswith("UNITS")][-1].split()[1:]])
+    assert out[0] == out[1] == out[2] and int(out[0][1]) >= 1 and len(set(out[0][i] for i in (0, 2, 3))) == 3
+    # preload 1: four in c3d_create, nothing more for the default job, +2 for the other potential, +2 for fp64 and embedding, nothing for a second context
+    assert units[0] == [4, 4, 6, 8, 8], units[0]
+    assert units[1] == [0, 4, 6, 8, 8], units[1]          # preload 0: the same units, each at the entry that needed it
+    assert units[2] == [16, 16, 16, 16, 16], units[2]     # preload 2: everything in c3d_create
 
 
 def test_model_struct_with_a_zero_last_member_means_the_default(solver):
