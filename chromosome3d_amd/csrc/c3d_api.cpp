@@ -592,6 +592,27 @@ int launch_op(c3d_ctx* c, const Op& op, int g, int par) {
     return C3D_OK;
 }
 
+// The multi-step kernel's geometry for the context's beads, replicas, XCD set AND model (the device potential decides which column
+// layouts and geometries exist: cluster_plan), and the record buffer it needs.  c3d_init_replicas plans when it allocates; c3d_set_model
+// plans again when replicas exist (round 6: a model with another potential installed between two c3d_init_replicas calls of the same
+// replica count used to keep the old potential's plan — "cluster launch: invalid argument" at the next c3d_run_steps).
+int plan_cluster(c3d_ctx* c) {
+    c3d::DevModel m = dev_model(c);
+    m.nrep = c->nrep; m.nrep_g = c->nrep; m.rep_base = 0;
+    c->cl_ok = c3d::cluster_plan(m, c->num_cus, c->num_xcc, c->cluster_geom, c->cluster_late, c->xcd_count, &c->cl_plan);
+    if (!c->cl_ok) return C3D_OK;
+    c->cl_plan.device = c->device;
+    const size_t bytes = c3d::cluster_record_bytes(m, c->cl_plan);
+    if (!c->d_crec || bytes > c->crec_bytes) {
+        if (c->d_crec) { HIP_TRY(hipStreamSynchronize(c->stream)); dev_free(c->d_crec); }
+        c->crec_bytes = 0;
+        HIP_TRY(hipMalloc(&c->d_crec, bytes));
+        c->crec_bytes = bytes;
+    }
+    c->cl_seq = 0;                             // the next launch wipes the records and the slot counters
+    return C3D_OK;
+}
+
 // Can the ops run as one k_cluster launch (a replica on a few 1024-thread workgroups of one XCD)?
 bool cluster_ok(c3d_ctx* c) {
     if (!c->resident || !c->cluster || !c->cl_ok || !c->d_crec) return false;
@@ -1055,6 +1076,10 @@ extern "C" int c3d_set_model(c3d_ctx* c, const c3d_model* m) {
     c->model.msoexp = msoexp;
     dev_free(c->buf.tgs2);                 // the pre-scaled pair targets of the per-step kernel carry 1 / mrs: rebuilt on demand
     build_program(c);
+    if (c->have_replicas) {                // the multi-step kernel's plan depends on the potential
+        HIP_TRY(hipSetDevice(c->device));
+        if (int rc = plan_cluster(c)) return rc;
+    }
     if (c->precision == 64 && c->b64.T) {                              // the fp64 target matrix encodes "no restraint" per potential
         C3D_ENTRY(c, 0u);
         return build_targets64(c);
@@ -1335,13 +1360,7 @@ extern "C" int c3d_init_replicas(c3d_ctx* c, int nrep, uint64_t seed, uint32_t f
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 HIP_TRY(hipMalloc(&c->d_sym_scratch, sizeof(float) * c3d::sym_scratch_floats(m)));
             }
-            c->cl_ok = c3d::cluster_plan(m, c->num_cus, c->num_xcc, c->cluster_geom, c->cluster_late, c->xcd_count, &c->cl_plan);
-            if (c->cl_ok) {
-                c->cl_plan.device = c->device;
-                c->crec_bytes = c3d::cluster_record_bytes(m, c->cl_plan);
-                HIP_TRY(hipMalloc(&c->d_crec, c->crec_bytes));
-                c->cl_seq = 0;                     // the first launch wipes the records and the slot counters
-            }
+            if (int rc = plan_cluster(c)) return rc;
         }
         c->have_replicas = true;
     }
