@@ -426,30 +426,31 @@ def test_headline_kernel_follows_the_oracle_at_the_headline_size(solver, O):
         solver.set_option("resident", -1)
 
 
-@pytest.mark.parametrize("resident", [1, 0])
-def test_two_point_kernel_follows_the_oracle_at_the_headline_size(solver, O, resident):
+@pytest.mark.parametrize("resident,cid,kernel", [(1, "chr1_500kb", "<4, 4, 2, 3, "), (0, "chr1_500kb", ""), (1, "chr4_1mb", "<4, ")])
+def test_two_point_kernel_follows_the_oracle_at_the_headline_size(solver, O, resident, cid, kernel):
     """The final stage as the shipped schedule runs it (chromosome3D.pl:1790-1803; kind 5), held to the CPU restatement where it runs:
     chr1_500kb x 20, a short MD stage away from the coil, then a kind-5 stage of 30 steps with the hand-over to FIRE after 12 of them —
     the two-point steps on k_cluster_tp (the instantiation every default chr1_500kb anneal spends 1000 steps in; round 5 compared it with
     the oracle at N <= 96 only), the hand-over (kind 3 at step 12: run_ops splits the range there, FIRE's part re-enters k_cluster), then
-    18 FIRE steps; every one of the 20 replicas, at the hand-over and at the end.  resident = 0: the same through the per-step kernel."""
+    18 FIRE steps; every one of the 20 replicas, at the hand-over and at the end.  resident = 0: the same through the per-step kernel;
+    chr4_1mb x 20 (N = 189: one column block, another geometry) through the multi-step kernels as well."""
     stages = [(0, 12, 0.003, 0.4, 0.003, 0.9, 2000.0), (5, 30, 0.0, 1.0, 1.0, 0.85, 0.0)]
     solver.set_option("final_minimiser_steps", 12)
     O.set_two_point_steps(12)
     try:
-        IF, d10, m, fire = _setup(solver, "chr1_500kb", stages, nrep=20)
+        IF, d10, m, fire = _setup(solver, cid, stages, nrep=20)
         solver.set_option("resident", resident)
         x0 = solver.coords()
         assert solver.run_steps(24) == 24                    # MD + the two-point part
         if resident:
-            assert solver.step_kernel_name.startswith("c3d::k_cluster_tp<4, 4, 2, 3, "), solver.step_kernel_name
+            assert solver.step_kernel_name.startswith("c3d::k_cluster_tp" + kernel), solver.step_kernel_name
             assert solver.stat("last_path") == 2 and solver.last_timing()[2] == 2       # two launches: k_cluster (MD), k_cluster_tp
         else:
             assert solver.step_kernel_name.startswith("c3d::k_step<"), solver.step_kernel_name
         x_mid = solver.coords()
         assert solver.run_steps(10 ** 6) == 18               # the hand-over and FIRE
         if resident:
-            assert solver.step_kernel_name.startswith("c3d::k_cluster<4, 4, 2, 3, "), solver.step_kernel_name
+            assert solver.step_kernel_name.startswith("c3d::k_cluster" + kernel), solver.step_kernel_name
         x_end = solver.coords()
         om, of = oracle_model_from(m, IF.shape[0]), oracle_fire_from(fire)
         head = [stages[0], (5, 12, 0.0, 1.0, 1.0, 0.85, 0.0)]
