@@ -19,11 +19,11 @@ use File::Basename;
 use File::Copy;
 use Getopt::Long;
 
-my ($help, $dir_out, $file_if, $shape_only, $file_seq);
+my ($help, $dir_out, $file_if, $shape_only, $file_seq, $accepted);
 my ($K, $ALPHA, $MODELS) = (11, 0.5, 20);        # chromosome3D.pl:18-21
 my ($SEED, $DEVICE, $DISTRELAX) = (82364, 0, 0.5);  # :980, :74
 GetOptions("h" => \$help, "o=s" => \$dir_out, "k=i" => \$K, "a=s" => \$ALPHA, "m=i" => \$MODELS,
-           "i|if=s" => \$file_if, "seed=i" => \$SEED, "device=i" => \$DEVICE, "shape=s" => \$shape_only, "seq=s" => \$file_seq)
+           "i|if=s" => \$file_if, "seed=i" => \$SEED, "device=i" => \$DEVICE, "shape=s" => \$shape_only, "seq=s" => \$file_seq, "accepted" => \$accepted)
 	or die "ERROR! Error in command line arguments!\n";
 usage() if $help;
 # residue names a model row may carry (the 20 standard amino acids; rows with any other name are dropped, reference :847)
@@ -64,7 +64,7 @@ my $ID = basename($file_if, ".txt");
 die "ERROR! the matrix file's name may hold letters, digits, '_', '.', '+' and '-' only: '$ID'\n" unless $ID =~ /^[\w.+-]+$/;
 # the reference wipes the whole output directory (`rm -f $dir_out/*`, :56); we only remove what a
 # previous run of this driver left there
-unlink glob("$dir_out/${ID}_*.pdb"), glob("$dir_out/iam.*");
+unlink glob("$dir_out/${ID}_*.pdb"), glob("$dir_out/${ID}a_*.pdb"), glob("$dir_out/iam.*");
 unlink map { "$dir_out/$_" } ("$ID.dist", "$ID.rr", "contact.tbl", "job.sh", "job.log", "model_info.log", "contact_violation.txt");
 copy($file_if, "$dir_out/$ID.txt") or die "ERROR! cannot copy $file_if: $!\n" if abs_path($file_if) ne (abs_path("$dir_out/$ID.txt") || "");
 chdir $dir_out or die $!;
@@ -106,6 +106,7 @@ if ($have_xs) {
 		die "ERROR! Something went wrong inside libc3d: $@";
 	}
 	unlink "iam.running";
+	if ($accepted) { copy("${ID}_$_.pdb", "${ID}a_$_.pdb") or die "ERROR! cannot write ${ID}a_$_.pdb: $!\n" foreach (1 .. $MODELS); }   # (-accepted: see below)
 	$restraints = $r->{restraints};
 	open my $jl, ">", "job.log" or die $!;
 	printf $jl "C3D XS binding: %d beads, %d restraints, %d models, %d SA steps in %.1f ms on device %d\n", $r->{n}, $r->{restraints}, $MODELS, $r->{steps}, $r->{ms}, $DEVICE;
@@ -116,14 +117,15 @@ else {
 open my $job, ">", "job.sh" or die $!;
 print $job "#!/bin/bash\necho \"starting c3d_solve..\"\ntouch iam.running\n";
 # every string argument single-quoted for the shell; the residue names travel as the file written above, never as text on the line
-print $job shq($solver)." --if ".shq("$ID.txt")." --out . --id ".shq($ID)." -k ".($K+0)." -a ".($ALPHA+0)." -m ".int($MODELS)." --seed ".int($SEED)." --device ".int($DEVICE).(defined $file_seq ? " --seq ".shq("\@$ID.fasta") : "")."\n";
+print $job shq($solver)." --if ".shq("$ID.txt")." --out . --id ".shq($ID)." -k ".($K+0)." -a ".($ALPHA+0)." -m ".int($MODELS)." --seed ".int($SEED)." --device ".int($DEVICE).(defined $file_seq ? " --seq ".shq("\@$ID.fasta") : "").($accepted ? " --accepted" : "")."\n";
 print $job "if [ -f ".shq("${ID}_".int($MODELS).".pdb")." ]; then\n   rm -f iam.running\n   echo \"trial structures written.\"\n   exit\nfi\n";
+print $job "if [ -f ".shq("${ID}a_".int($MODELS).".pdb")." ]; then\n   rm -f iam.running\n   echo \"accepted structures written.\"\n   exit\nfi\n";   # (:272-277)
 print $job "echo \"ERROR! Final structures not found!\"\nmv iam.running iam.failed 2>/dev/null || touch iam.failed\n";
 close $job;
 chmod 0755, "job.sh";
 print "(B) Build models using libc3d (MI355X)..\nStarting job [$dir_out/job.sh > job.log]\n";
 system("./job.sh > job.log 2>&1");
-die "ERROR! Something went wrong while running c3d_solve! Check job.log!\n".`tail -n 5 job.log` if -f "iam.failed" or not -f "${ID}_${MODELS}.pdb";
+die "ERROR! Something went wrong while running c3d_solve! Check job.log!\n".`tail -n 5 job.log` if -f "iam.failed" or not (-f "${ID}_${MODELS}.pdb" or -f "${ID}a_${MODELS}.pdb");
 ($restraints) = `cat job.log` =~ /Restraints : (\d+)/;
 }
 tick("(B) build models");
@@ -132,8 +134,16 @@ print "Restraints : ".($restraints // "?")." lines in tbl file\n";
 
 # (C) assess models: rank by int(REMARK noe) ascending (:796-802), table (:804-810), top 5 (:822-828)
 print "(C) Assess models..\n";
+# remove the "trial" structure of a corresponding "accepted" structure because they are the same (:790-795).  libc3d writes accepted twins
+# only when asked (-accepted: CNS's acceptance thresholds are defined on covalent geometry a bead model does not have, so every model is
+# accepted then); the ranking below then runs on the <ID>a_<k>.pdb files, as the reference's does for structures CNS accepted
+for my $i (0 .. 1000) {
+	next if not -f "${ID}a_$i.pdb";
+	print "\ndeleting ${ID}_$i.pdb because ${ID}a_$i.pdb exists!";
+	unlink "./${ID}_$i.pdb";
+}
 my %e_noe;
-foreach my $pdb (glob("./${ID}_*.pdb")) {
+foreach my $pdb (glob("./${ID}_*.pdb"), glob("./${ID}a_*.pdb")) {
 	next if $pdb =~ /_model\d+\.pdb$/;
 	open my $fh, "<", $pdb or die $!;
 	my $v;
@@ -262,6 +272,8 @@ PARAM        DESCRIPTION
 -m        :  Number of models to generate (default 20)
 --seed    :  RNG seed (default 82364)   --device : GPU index (default 0)
 --seq     :  FASTA file naming the residues (the reference's pseudo-protein: chromosome3d_amd/data/refsequence.fasta; default: all MET)
+--accepted:  also write the accepted twin <ID>a_<k>.pdb of every model, as CNS does for structures it accepts; the trial twins are then dropped and
+             the accepted files ranked, as the reference's assess_dgsa does (default: trial files only)
 Example: $0 -i ./input/chr22_1mb_matrix.txt -o ./output/chr22_1mb
 EOU
 	exit(defined $msg ? 1 : 0);

@@ -24,7 +24,8 @@ static void usage() {
             "usage: c3d_solve (--if <IF matrix> | --tbl <contact.tbl> --n <beads>) --out <dir> [--id <ID>]\n"
             "                 [-k <K=11>] [-a <alpha=0.5>] [-m <models=20>] [--seed <82364>] [--first-replica <0>]\n"
             "                 [--device <0>] [--min-steps <3000>] [--gtol <1e-2>] [--final-minimiser <1>] [--embed] [--no-graph] [--quiet]\n"
-            "                 [--seq <one-letter residue codes | @fasta file>   residue names of the models (default: all MET)]\n");
+            "                 [--seq <one-letter residue codes | @fasta file>   residue names of the models (default: all MET)]\n"
+            "                 [--accepted   also write <ID>a_<k>.pdb beside every <ID>_<k>.pdb, as CNS does for structures it accepts]\n");
 }
 
 #define CHECK(call)                                                              \
@@ -56,7 +57,7 @@ int main(int argc, char** argv) {
     std::string if_path, tbl_path, out_dir, id, seq_arg;
     double K = 11, alpha = 0.5, gtol = 1e-2;
     int final_min = 1;
-    int models = 20, device = 0, n_beads = 0, min_steps = 3000, use_graph = 1, quiet = 0, embed = 0;
+    int models = 20, device = 0, n_beads = 0, min_steps = 3000, use_graph = 1, quiet = 0, embed = 0, accepted = 0;
     unsigned long long seed = 82364ULL;
     unsigned first_rep = 0;
     for (int a = 1; a < argc; ++a) {
@@ -82,6 +83,7 @@ int main(int argc, char** argv) {
         else if (s == "--embed") embed = 1;   // distance-geometry start (deck :1471-1525) instead of the random coil
         else if (s == "--no-graph") use_graph = 0;
         else if (s == "--quiet") quiet = 1;
+        else if (s == "--accepted") accepted = 1;   // the deck's printaccept writes <ID>a_<k>.pdb for structures CNS accepts, beside the trial file (:1818-1828)
         else if (s == "--seq") seq_arg = next("--seq");
         else if (s == "-h" || s == "--help") { usage(); return 0; }
         else { fprintf(stderr, "c3d_solve: unknown option %s\n", s.c_str()); usage(); return 2; }
@@ -158,12 +160,19 @@ int main(int argc, char** argv) {
         snprintf(name, sizeof name, "%s_%u.pdb", id.c_str(), first_rep + (unsigned)r + 1u);
         CHECK(c3d_write_pdb((out_dir + "/" + name).c_str(), xyz.data() + (size_t)r * n * 3, n, en[3 * r], en[3 * r + 1],
                             en[3 * r + 2], name));
+        if (accepted) {
+            // the accepted twin: same coordinates, same REMARK rows (the reference's assess_dgsa then drops the trial file, :791-795).  CNS's
+            // acceptance thresholds are defined on covalent geometry a bead model does not have: with --accepted every model is "accepted"
+            snprintf(name, sizeof name, "%sa_%u.pdb", id.c_str(), first_rep + (unsigned)r + 1u);
+            CHECK(c3d_write_pdb((out_dir + "/" + name).c_str(), xyz.data() + (size_t)r * n * 3, n, en[3 * r], en[3 * r + 1],
+                                en[3 * r + 2], name));
+        }
     }
     double ms = 0;
     long steps = 0, launches = 0;
     c3d_last_timing(ctx, &ms, &steps, &launches);
     if (!quiet) {
-        printf("trial structures written.\n");
+        printf(accepted ? "trial and accepted structures written.\n" : "trial structures written.\n");
         printf("c3d_solve: %d beads, %d restraints, %d models, %ld SA steps/model in %.1f ms on device %d (%.3g replica-steps/s)\n",
                n, R, models, steps, ms, device, ms > 0 ? 1e3 * (double)steps * models / ms : 0.0);
         if (IF) {

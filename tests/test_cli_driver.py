@@ -140,6 +140,42 @@ def test_batch_script_runs_every_matrix(built, tmp_path):
         assert len(list((tmp_path / "out" / cid).glob(f"{cid}_matrix_model*.pdb"))) == 5
 
 
+@pytest.mark.gpu
+def test_accepted_twins_are_written_deduplicated_and_ranked_as_the_reference_does(built, tmp_path):
+    """The reference's deck writes <ID>a_<k>.pdb beside <ID>_<k>.pdb for structures CNS accepts; job.sh takes either as success
+    (chromosome3D.pl:266-277) and assess_dgsa deletes the trial twin of every accepted file before it ranks (:790-795).  `c3d_solve
+    --accepted` / the driver's `-accepted` write the twins (every model: CNS's acceptance thresholds are defined on covalent geometry a
+    bead model does not have); through both binding routes the trial twins are gone afterwards, the accepted files were ranked, and the
+    five models are byte for byte those of a run without the option."""
+    if shutil.which("perl") is None:
+        pytest.skip("no perl on this box")
+    drv = os.path.join(ROOT, "bin", "chromosome3D_amd.pl")
+    cid = "chr21_1mb_matrix"
+    plain = tmp_path / "plain"
+    out = subprocess.run(["perl", drv, "-i", MATRIX, "-o", str(plain), "-m", "7"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for force_cli in ("0", "1"):
+        od = tmp_path / f"acc{force_cli}"
+        env = dict(os.environ, C3D_FORCE_CLI="1") if force_cli == "1" else {k: v for k, v in os.environ.items() if k != "C3D_FORCE_CLI"}
+        out = subprocess.run(["perl", drv, "-i", MATRIX, "-o", str(od), "-m", "7", "-accepted"], capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.count(f"deleting {cid}_") == 7 and f"because {cid}a_7.pdb exists!" in out.stdout
+        left = sorted(p.name for p in od.glob("*.pdb"))
+        assert sum(n.startswith(f"{cid}a_") for n in left) == 2 and sum("_model" in n for n in left) == 5 and len(left) == 7, left
+        picked = [l.split("<=")[1].strip() for l in out.stdout.splitlines() if l.startswith("model") and "<=" in l]
+        assert len(picked) == 5 and all(f"{cid}a_" in q for q in picked), picked
+        for k in range(1, 6):
+            assert open(od / f"{cid}_model{k}.pdb").read() == open(plain / f"{cid}_model{k}.pdb").read(), k
+    # the executable alone: both files of every model, same bytes but for the name rows
+    od = tmp_path / "solve"
+    out = subprocess.run([os.path.join(LIBDIR, "c3d_solve"), "--if", MATRIX, "--out", str(od), "-m", "3", "--accepted"], capture_output=True, text=True)
+    assert out.returncode == 0 and "trial and accepted structures written." in out.stdout, out.stdout + out.stderr
+    for k in (1, 2, 3):
+        a = [l for l in open(od / f"{cid}_{k}.pdb") if not l.startswith("REMARK FILENAME")]
+        b = [l for l in open(od / f"{cid}a_{k}.pdb") if not l.startswith("REMARK FILENAME")]
+        assert a == b and len(a) > 37
+
+
 def test_perl_driver_seq_option_cannot_reach_a_shell(built, tmp_path):
     """-seq <fasta> names residues (reference :93-98).  A hostile FASTA (stop codon '*', ';', '$( )', backticks) is refused before
     anything runs; a clean one travels to c3d_solve as `--seq '@<ID>.fasta'` — the file the driver wrote — and every string on the
