@@ -29,4 +29,17 @@ g++ -fsanitize=thread "$TMP/api.o" "$TMP/host.o" "$TMP/batch.o" "$TMP/stub.o" "$
 mkdir -p "$TMP/run"
 TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1" "$TMP/executor_tsan" "$TMP/run" > "$TMP/executor.log" 2>&1 || { tail -40 "$TMP/executor.log"; rm -rf "$TMP"; exit 1; }
 tail -1 "$TMP/executor.log"
+# the same harness under AddressSanitizer + UBSan (leaks included): the host code of the contexts and the executor touches no freed or foreign memory
+AF="-std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Wno-unused-result"
+g++ $AF -c "$CSRC/c3d_api.cpp" -o "$TMP/a_api.o" &
+g++ $AF -c "$CSRC/c3d_host.cpp" -o "$TMP/a_host.o" &
+g++ $AF -Dmain=c3d_batch_main -c "$CSRC/c3d_batch_main.cpp" -o "$TMP/a_batch.o" &
+g++ $AF -c "$HERE/hip_stub.cpp" -o "$TMP/a_stub.o" &
+g++ $AF -c "$HERE/executor_tsan_main.cpp" -o "$TMP/a_main.o" &
+wait
+g++ -fsanitize=address,undefined "$TMP/a_api.o" "$TMP/a_host.o" "$TMP/a_batch.o" "$TMP/a_stub.o" "$TMP/a_main.o" -o "$TMP/executor_asan" -lpthread
+mkdir -p "$TMP/run_asan"
+ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 "$TMP/executor_asan" "$TMP/run_asan" > "$TMP/executor_asan.log" 2>&1 || { tail -60 "$TMP/executor_asan.log"; rm -rf "$TMP"; exit 1; }
+echo "executor under ASan + UBSan: clean"
+tail -1 "$TMP/executor.log"
 rm -rf "$TMP"
