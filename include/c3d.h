@@ -157,8 +157,9 @@ int c3d_set_schedule(c3d_ctx* ctx, const c3d_stage* stages, int n_stages, const 
  *                   (measurement knob)
  *   prefetch_ranks  1 (default) / 0: c3d_set_if_matrix starts the IF side of the Spearman coefficient (average ranks of the matrix's ordered
  *                   pairs |i-j| >= 3, spearman_IF_pdb.pl:30-44: 5 ms of host time at N = 455) on a helper thread over a copy of the matrix;
- *                   c3d_score_replicas takes it when its IF argument holds the same numbers, else computes it as before.  Same result
- *                   either way (measurement knob; stat "rank_prefetch_hits")
+ *                   c3d_score_replicas takes it when its IF argument holds the same numbers, else computes it as before.  Up to 2048 beads
+ *                   only (the worker keeps 16 bytes per pair until the context goes: 67 MB there).  Same result either way
+ *                   (measurement knob; stat "rank_prefetch_hits")
  *   final_minimiser 1 (default) / 0: what a stage of kind 5 (the default schedule's final stage) runs — two-point step sizes handing over to
  *                   FIRE after final_minimiser_steps, or FIRE throughout as in rounds 1-4.  Stages of kind 2 are FIRE whatever this says
  *   final_minimiser_steps   1000 (default): two-point steps of a kind-5 stage before FIRE takes it over (>= 2)
