@@ -281,20 +281,22 @@ def test_batch_executor_per_device_lists_and_threads_rehearsed_on_one_gpu(built,
         write_if_text(load_if(c), pth)
         mats.append(str(pth))
     runs = {}
+    # "eight": the production shape of an 8-GPU node — 8 devices x 3 lanes = 24 contexts of one process — on this box's one device
     for tag, extra in (("one", ["--devices", "1", "--lanes", "1", "--pair", "0"]), ("four", ["--devices", "4", "--lanes", "2", "--map-devices-to", "0"]),
-                       ("paired", ["--devices", "1", "--lanes", "3"])):
+                       ("paired", ["--devices", "1", "--lanes", "3"]), ("eight", ["--devices", "8", "--lanes", "3", "--map-devices-to", "0"])):
         od = tmp_path / tag
         p = subprocess.run([exe] + mats + ["--out", str(od), "-m", "6"] + extra, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout + p.stderr
         assert "6 matrices x 6 models" in p.stdout and "0 failed" in p.stdout
         runs[tag] = (od, p.stdout)
-    assert "on 4 GPU(s), 2 lane(s) each" in runs["four"][1]
+    assert "on 4 GPU(s), 2 lane(s) each" in runs["four"][1] and "on 8 GPU(s), 3 lane(s) each" in runs["eight"][1]
     assert sorted(set(re.findall(r"GPU (\d)(?: XCDs \d-\d)?  \[phases", runs["four"][1]))) == ["0", "1", "2", "3"]      # every logical device took jobs
     for chrom in ("chr21_1mb", "chr22_1mb", "chr20_1mb", "chr13_1mb", "chr19_500kb", "chr21_500kb"):
         cid = chrom + "_matrix"
         for k in range(1, 6):
             assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["four"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
             assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["paired"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
+            assert open(runs["one"][0] / chrom / f"{cid}_model{k}.pdb").read() == open(runs["eight"][0] / chrom / f"{cid}_model{k}.pdb").read(), (chrom, k)
     # (round 5 ran the eight-context start seven times here to see whether its device exception came back; a pass by not reproducing a
     #  race is no evidence.  Round 6 removed what could race — c3d_create loads every code object a default job needs before it returns,
     #  no helper thread touches the runtime, loads and launches exclude one another: csrc/c3d_api.cpp "code objects" — and checks THAT on
