@@ -1,6 +1,7 @@
 // executor_tsan_main.cpp — libc3d's context code and the c3d_batch executor under ThreadSanitizer, on the CPU, against the fake HIP layer
 // of hip_stub.cpp (tools/sanitize/run.sh builds and runs it).
 //
+//   0. a code object that fails to load: c3d_create reports it (C3D_ERR_HIP, message naming the unit) and does not remember it as loaded
 //   1. c3d_batch --devices 4 --lanes 2 --map-devices-to 0   eight contexts of one process starting together on one device: the start that
 //                                                           met a device exception on the GPU box in round 5
 //   2. c3d_batch --devices 8 --lanes 3                      the production shape on an 8-GPU node: 24 contexts (the stub shows 8 devices)
@@ -23,6 +24,7 @@
 
 int c3d_batch_main(int argc, char** argv);          // c3d_batch_main.cpp built with -Dmain=c3d_batch_main
 extern "C" long c3d_stub_violations();
+extern "C" void c3d_stub_fail_next_loads(int n);
 extern "C" long c3d_stub_launches();
 extern "C" long c3d_stub_loads();
 extern "C" long c3d_stub_cluster_launches();
@@ -106,15 +108,28 @@ int main(int argc, char** argv) {
         write_matrix(p, sizes[k], 100u + (unsigned)k);
         mats.push_back(p);
     }
-    // 1. the start of round 5's exception: eight contexts, one device
+    // 0. a code object that fails to load is reported by c3d_create — and not remembered as loaded: the next c3d_create loads it
     setenv("C3D_STUB_DEVICES", "1", 1);
+    {
+        c3d_stub_fail_next_loads(2);                    // the next two load attempts report an error: two c3d_create calls fail at their first unit
+        c3d_ctx* c = nullptr;
+        REQ(c3d_create(0, &c) == C3D_ERR_HIP && c == nullptr);
+        REQ(strstr(c3d_last_error(), "loading the code object of the") != nullptr);
+        REQ(c3d_create(0, &c) == C3D_ERR_HIP && c == nullptr);
+        REQ(c3d_create(0, &c) == C3D_OK && c != nullptr);
+        double loaded = -1;
+        REQ(c3d_get_stat(c, "units_loaded", &loaded) == C3D_OK && loaded == 4.0);
+        c3d_destroy(c);
+    }
+    const long failed_attempts = 2;
+    // 1. the start of round 5's exception: eight contexts, one device
     {
         std::vector<std::string> a = mats;
         a.insert(a.end(), {"--out", tmp + "/four", "-m", "6", "--devices", "4", "--lanes", "2", "--map-devices-to", "0"});
         REQ(run_batch(a) == 0);
     }
     const long loads_one_device = c3d_stub_loads();
-    REQ(loads_one_device == 4);                       // the default job's four units, once for the process: nobody loaded anything later
+    REQ(loads_one_device == 4 + failed_attempts);     // the default job's four units, once for the process (+ the two attempts that were made to fail): nobody loaded anything later
     // 2. the production shape: 8 devices x 3 lanes
     setenv("C3D_STUB_DEVICES", "8", 1);
     {
@@ -122,7 +137,7 @@ int main(int argc, char** argv) {
         a.insert(a.end(), {"--out", tmp + "/eight", "-m", "6", "--devices", "8", "--lanes", "3"});
         REQ(run_batch(a) == 0);
     }
-    REQ(c3d_stub_loads() == 4 + 4 * 7);               // device 0 had them; seven more devices x four units
+    REQ(c3d_stub_loads() == 4 + failed_attempts + 4 * 7);   // device 0 had them; seven more devices x four units
     // 3. configurations that want other units, from twelve threads at once
     api_storm(8);
     printf("executor under TSan: %ld launches (%ld multi-step), %ld unit loads, %ld load/launch overlaps\n", c3d_stub_launches(),

@@ -34,6 +34,7 @@ struct LaunchScope {
     }
     ~LaunchScope() { g_launching.fetch_sub(1); }
 };
+std::atomic<int> g_fail_next_load{0};          // c3d_stub_fail_next_loads(n): the next n unit loads report an error (the loader's error path)
 struct LoadScope {
     LoadScope() {
         g_loading.fetch_add(1);
@@ -53,6 +54,12 @@ thread_local int t_device = 0;
 }  // namespace
 
 extern "C" long c3d_stub_violations() { return g_violations.load(); }
+extern "C" void c3d_stub_fail_next_loads(int n) { g_fail_next_load.store(n); }
+static hipError_t load_result() {
+    int left = g_fail_next_load.load();
+    while (left > 0 && !g_fail_next_load.compare_exchange_weak(left, left - 1)) { }
+    return left > 0 ? hipErrorSharedObjectInitFailed : hipSuccess;
+}
 extern "C" long c3d_stub_launches() { return g_launches.load(); }
 extern "C" long c3d_stub_loads() { return g_loads.load(); }
 extern "C" long c3d_stub_cluster_launches() { return g_cluster_launches.load(); }
@@ -98,13 +105,13 @@ hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { LaunchScope ls; return 
 // ---- the kernels' translation units: launchers that launch nothing, loaders that load nothing -------------------------------------
 namespace c3d {
 
-hipError_t preload_device_unit() { LoadScope l; return hipSuccess; }
-hipError_t preload_cluster_base_unit() { LoadScope l; return hipSuccess; }
-hipError_t preload_cluster_unit(int pot, bool) { LoadScope l; return pot >= 0 && pot <= 4 ? hipSuccess : hipErrorInvalidValue; }
-hipError_t preload_score_unit() { LoadScope l; return hipSuccess; }
-hipError_t preload_embed_unit() { LoadScope l; return hipSuccess; }
-hipError_t preload_f64_unit() { LoadScope l; return hipSuccess; }
-hipError_t preload_sym_unit() { LoadScope l; return hipSuccess; }
+hipError_t preload_device_unit() { LoadScope l; return load_result(); }
+hipError_t preload_cluster_base_unit() { LoadScope l; return load_result(); }
+hipError_t preload_cluster_unit(int pot, bool) { LoadScope l; return pot >= 0 && pot <= 4 ? load_result() : hipErrorInvalidValue; }
+hipError_t preload_score_unit() { LoadScope l; return load_result(); }
+hipError_t preload_embed_unit() { LoadScope l; return load_result(); }
+hipError_t preload_f64_unit() { LoadScope l; return load_result(); }
+hipError_t preload_sym_unit() { LoadScope l; return load_result(); }
 
 hipError_t launch_step(const DevModel&, const DevStep&, const DevFire&, const DevBuffers&, int, bool, bool, hipStream_t) { LaunchScope ls; return hipSuccess; }
 hipError_t launch_eval_forces(const DevModel&, const DevStep&, const DevBuffers&, int, float*, bool, int, hipStream_t) { LaunchScope ls; return hipSuccess; }
