@@ -414,7 +414,8 @@ int active_groups(const c3d_ctx* c) { return std::min(c->ngroups, std::max(c->nr
 //   * every public entry that issues device work (kernels, copies, fills) holds g_units.rw SHARED for its whole duration (struct Entry)
 //     and names the units it can need before it takes it: a unit is never loaded while any thread of the process can launch;
 //   * c3d_create loads what a default job runs (per-step + K1 unit, both multi-step units of the shipped potential, scoring) before it
-//     returns — ~9 ms once per process and device (c3d_set_process_option "preload": 2 = all sixteen, 0 = each at the first entry that
+//     returns — 13 ms once per process and device, 24 ms for all sixteen: profiles/r06_create_with_code_objects.txt (c3d_set_process_option
+//     "preload": 2 = all sixteen, 0 = each at the first entry that
 //     needs it); the multi-step and embedding units also get their dynamic-LDS allowance there (hipFuncSetAttribute per instantiation:
 //     state of the runtime, so it belongs under the same lock), and a launch changes no runtime state afterwards;
 //   * a load that fails is reported (C3D_ERR_HIP) and not remembered as done.
@@ -1027,7 +1028,7 @@ extern "C" int c3d_create(int device, c3d_ctx** out) {
         return fail(C3D_ERR_HIP, "cannot create HIP stream/events");
     }
     // Code objects ("code objects" above): what a default job launches from is loaded HERE, on this thread, before the caller can launch
-    // anything — not by a helper thread beside the caller's first launches, as in rounds 4-5 (that saved the first job of a process ~9 ms
+    // anything — not by a helper thread beside the caller's first launches, as in rounds 4-5 (that saved the first job of a process ~13 ms
     // and is where the one device exception of round 5 was met).  Later contexts of the device find the units loaded (one atomic load).
     {
         const int pre = g_preload.load();
